@@ -1,0 +1,340 @@
+"""ctypes face of the CPU oracle (oracle/pebble_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by pebblesdr_amd.  See oracle/pebble_oracle.h for what it restates and how it is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpebble_oracle.so")
+
+AM, SAM, FMN, FMM, FMS, DSB, LSB, USB, CWL, CWU, DIGL, DIGU, NONE = range(13)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few hundred ms).  Safe to call repeatedly."""
+    src = [os.path.join(_HERE, f) for f in ("pebble_oracle.c", "pebble_oracle.h", "hb_taps.h")]
+    if (not force) and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpebble_oracle.so"])
+    return _SO
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.po_decimator_new.restype = C.c_void_p
+        L.po_decimator_free.argtypes = [C.c_void_p]
+        L.po_decimator_build.restype = C.c_double
+        L.po_decimator_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.po_decimator_chain_len.argtypes = [C.c_void_p]
+        L.po_decimator_dec_by2_stages.restype = C.c_uint32
+        L.po_decimator_dec_by2_stages.argtypes = [C.c_void_p]
+        L.po_decimator_stage.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.po_decimator_process.restype = C.c_uint32
+        L.po_decimator_process.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.po_fft.argtypes = [_dp, C.c_uint32, C.c_int]
+        L.po_fastfir_new.restype = C.c_void_p
+        L.po_fastfir_new.argtypes = [C.c_uint32, C.c_uint32]
+        L.po_fastfir_free.argtypes = [C.c_void_p]
+        L.po_fastfir_setup.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.po_fastfir_process.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.po_fastfir_coef.restype = _dp
+        L.po_fastfir_coef.argtypes = [C.c_void_p]
+        L.po_spectrum_new.restype = C.c_void_p
+        L.po_spectrum_new.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+        L.po_spectrum_free.argtypes = [C.c_void_p]
+        L.po_spectrum_bins.restype = C.c_uint32
+        L.po_spectrum_bins.argtypes = [C.c_void_p]
+        L.po_spectrum_coherent_gain.restype = C.c_double
+        L.po_spectrum_coherent_gain.argtypes = [C.c_void_p]
+        L.po_spectrum_window.restype = _dp
+        L.po_spectrum_window.argtypes = [C.c_void_p]
+        L.po_spectrum_process.argtypes = [C.c_void_p, _dp, C.c_uint32, _dp]
+        L.po_receiver_new.restype = C.c_void_p
+        L.po_receiver_new.argtypes = [C.c_uint32] * 5
+        L.po_receiver_free.argtypes = [C.c_void_p]
+        L.po_receiver_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.po_receiver_set_mixer.argtypes = [C.c_void_p, C.c_double]
+        L.po_receiver_set_filter.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.po_receiver_demod_rate.restype = C.c_double
+        L.po_receiver_demod_rate.argtypes = [C.c_void_p, C.c_int]
+        L.po_receiver_dec_stages.restype = C.c_uint32
+        L.po_receiver_dec_stages.argtypes = [C.c_void_p, C.c_int]
+        L.po_receiver_process.restype = C.c_uint32
+        L.po_receiver_process.argtypes = [C.c_void_p, _dp, C.c_uint32, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _c128(x):
+    return np.ascontiguousarray(x, dtype=np.complex128)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class _MixerS(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fs", "freq", "inc", "osc_cos", "osc_sin", "last_re", "last_im")]
+
+
+class Mixer:
+    """pebblelib/mixer.cpp"""
+
+    def __init__(self, fs):
+        self.s = _MixerS()
+        lib().po_mixer_init(C.byref(self.s), C.c_double(fs))
+
+    def set_frequency(self, f):
+        lib().po_mixer_set_frequency(C.byref(self.s), C.c_double(f))
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        r = lib().po_mixer_process(C.byref(self.s), _ptr(x), _ptr(out), C.c_uint32(len(x)))
+        return out if r else x.copy()
+
+
+class Decimator:
+    """pebblelib/decimator.cpp (vDSP path)"""
+
+    def __init__(self, fs_in, protect_bw, fs_out_min=0):
+        self.h = lib().po_decimator_new()
+        self.rate = lib().po_decimator_build(self.h, int(fs_in), int(protect_bw), int(fs_out_min))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_decimator_free(self.h)
+            self.h = None
+
+    @property
+    def dec_by2_stages(self):
+        return lib().po_decimator_dec_by2_stages(self.h)
+
+    def chain(self):
+        """[(ntaps, stride)] -- ntaps 0 means CIC3"""
+        out = []
+        for i in range(lib().po_decimator_chain_len(self.h)):
+            nt, st, de = C.c_int(), C.c_uint32(), C.c_int()
+            lib().po_decimator_stage(self.h, i, C.byref(nt), C.byref(st), C.byref(de))
+            out.append((nt.value, st.value))
+        return out
+
+    @property
+    def total_decimation(self):
+        d = 1
+        for _, s in self.chain():
+            d *= s
+        return d
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty(len(x) + 8, dtype=np.complex128)
+        n = lib().po_decimator_process(self.h, _ptr(x), _ptr(out), C.c_uint32(len(x)))
+        return out[:n].copy()
+
+
+def fft(x, inverse=False):
+    x = _c128(x).copy()
+    lib().po_fft(_ptr(x), C.c_uint32(len(x)), C.c_int(-1 if inverse else 1))
+    return x
+
+
+class FastFIR:
+    """pebblelib/fastfir.cpp"""
+
+    def __init__(self, fft_size=2048, fir_size=1025):
+        self.fft_size, self.fir_size = fft_size, fir_size
+        self.h = lib().po_fastfir_new(fft_size, fir_size)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_fastfir_free(self.h)
+            self.h = None
+
+    def setup(self, lo, hi, offset, fs):
+        return lib().po_fastfir_setup(self.h, lo, hi, offset, fs)
+
+    def coef(self):
+        p = lib().po_fastfir_coef(self.h)
+        return np.ctypeslib.as_array(p, shape=(2 * self.fft_size,)).view(np.complex128).copy()
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty(len(x) + self.fft_size, dtype=np.complex128)
+        n = lib().po_fastfir_process(self.h, len(x), _ptr(x), _ptr(out))
+        return out[:n].copy()
+
+
+class Spectrum:
+    """FFT::fftSpectrum (pebblelib/fft.cpp) as SignalSpectrum configures it"""
+
+    def __init__(self, fft_size, samples_per_buffer, window=True, lift_clamp=False):
+        self.h = lib().po_spectrum_new(fft_size, samples_per_buffer, 0 if window else 1, 1 if lift_clamp else 0)
+        self.bins = lib().po_spectrum_bins(self.h)
+        self.spb = samples_per_buffer
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_spectrum_free(self.h)
+            self.h = None
+
+    @property
+    def coherent_gain(self):
+        return lib().po_spectrum_coherent_gain(self.h)
+
+    def window(self):
+        return np.ctypeslib.as_array(lib().po_spectrum_window(self.h), shape=(self.spb,)).copy()
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty(self.bins, dtype=np.float64)
+        lib().po_spectrum_process(self.h, _ptr(x), len(x), _ptr(out))
+        return out
+
+
+class _FirS(C.Structure):
+    _fields_ = [("ntaps", C.c_int), ("state", C.c_int), ("coef", C.c_double * 150),
+                ("zre", C.c_double * 75), ("zim", C.c_double * 75)]
+
+
+class Fir:
+    """pebblelib/fir.cpp CFir (low-pass design + complex process)"""
+
+    def __init__(self):
+        self.s = _FirS()
+
+    def init_lp(self, ntaps, scale, astop, fpass, fstop, fs):
+        f = lib().po_fir_init_lp
+        f.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 5
+        return f(C.byref(self.s), ntaps, scale, astop, fpass, fstop, fs)
+
+    def taps(self):
+        return np.array(self.s.coef[: self.s.ntaps])
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_fir_process_cpx(C.byref(self.s), C.c_int(len(x)), _ptr(x), _ptr(out))
+        return out
+
+
+class _IirS(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("a1", "a2", "b0", "b1", "b2", "w1a", "w2a", "w1b", "w2b")]
+
+
+class Iir:
+    """pebblelib/iir.cpp CIir"""
+
+    def __init__(self, kind, f0, q, fs):
+        self.s = _IirS()
+        f = getattr(lib(), "po_iir_init_" + kind)
+        f.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        f(C.byref(self.s), f0, q, fs)
+
+    def coeffs(self):
+        return (self.s.b0, self.s.b1, self.s.b2, self.s.a1, self.s.a2)
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_iir_process_cpx(C.byref(self.s), C.c_int(len(x)), _ptr(x), _ptr(out))
+        return out
+
+
+class _AmS(C.Structure):
+    _fields_ = [("fs", C.c_double), ("dc", C.c_double), ("dc_last", C.c_double), ("lp", _FirS)]
+
+
+class DemodAM:
+    """application/demod/demod_am.cpp processBlockFiltered"""
+
+    def __init__(self, fs, bandwidth=None):
+        self.s = _AmS()
+        lib().po_demod_am_init(C.byref(self.s), C.c_double(fs))
+        if bandwidth is not None:
+            self.set_bandwidth(bandwidth)
+
+    def set_bandwidth(self, bw):
+        lib().po_demod_am_set_bandwidth(C.byref(self.s), C.c_double(bw))
+
+    @property
+    def ntaps(self):
+        return self.s.lp.ntaps
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_demod_am_process(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
+        return out
+
+
+class _WfmS(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fs", "d1_re", "d1_im", "deemph_alpha", "deemph_re", "deemph_im")] + \
+               [("mono_lp", _IirS), ("notch", _IirS), ("lp", _FirS)]
+
+
+class DemodWFM:
+    """application/demod/demod_wfm.cpp processDataMono"""
+
+    def __init__(self, fs):
+        self.s = _WfmS()
+        lib().po_demod_wfm_init(C.byref(self.s), C.c_double(fs))
+
+    @property
+    def ntaps(self):
+        return self.s.lp.ntaps
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_demod_wfm_process_mono(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
+        return out
+
+
+class Receiver:
+    """Receiver::processIQData DSP skeleton (application/receiver.cpp:758-1009)"""
+
+    def __init__(self, fs, frames_per_buffer=2048, spectrum_bins=4096, fastfir_fft=2048, fastfir_taps=1025):
+        self.n = frames_per_buffer
+        self.bins = max(2048, spectrum_bins) if spectrum_bins else 0
+        self.cap = max(frames_per_buffer, fastfir_fft)
+        self.h = lib().po_receiver_new(int(fs), frames_per_buffer, spectrum_bins, fastfir_fft, fastfir_taps)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_receiver_free(self.h)
+            self.h = None
+
+    def set_mode(self, mode):
+        lib().po_receiver_set_mode(self.h, mode)
+
+    def set_mixer(self, f):
+        lib().po_receiver_set_mixer(self.h, f)
+
+    def set_filter(self, lo, hi):
+        return lib().po_receiver_set_filter(self.h, lo, hi)
+
+    def demod_rate(self, wfm=False):
+        return lib().po_receiver_demod_rate(self.h, 1 if wfm else 0)
+
+    def dec_stages(self, wfm=False):
+        return lib().po_receiver_dec_stages(self.h, 1 if wfm else 0)
+
+    def process(self, frame, want_spectrum=True):
+        """one frame -> (audio ndarray (possibly empty), spectrum ndarray or None)"""
+        x = _c128(frame)
+        audio = np.empty(self.cap, dtype=np.complex128)
+        spec = np.empty(self.bins, dtype=np.float64) if (want_spectrum and self.bins) else None
+        n = lib().po_receiver_process(self.h, _ptr(x), len(x), _ptr(audio), _ptr(spec) if spec is not None else None)
+        return audio[:n].copy(), spec

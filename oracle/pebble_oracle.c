@@ -1,0 +1,719 @@
+/*
+ * pebble_oracle.c -- CPU restatement (fp64, scalar C) of PebbleSDR's per-frame IQ receive chain.
+ * TEST INFRASTRUCTURE ONLY -- see pebble_oracle.h for the rules and the parity-pinning status.
+ * Written from scratch from a reading of the reference; each function cites what it restates.
+ */
+#include "pebble_oracle.h"
+#include "hb_taps.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* pebblelib/cpx.h:16-19 */
+#define PO_PI 3.14159265358979323846264338328
+#define PO_TWOPI 6.28318530717958647692528676656
+
+/* ------------------------------------------------------------------------------------------------
+ * Mixer -- pebblelib/mixer.cpp
+ * ---------------------------------------------------------------------------------------------- */
+void po_mixer_init(po_mixer *m, double fs)
+{
+    memset(m, 0, sizeof(*m));
+    m->fs = fs;
+    po_mixer_set_frequency(m, 0.0); /* ctor: setFrequency(0), mixer.cpp:13 */
+}
+
+/* mixer.cpp:25-40: sign flip, step phasor, oscillator reset to (1,0) */
+void po_mixer_set_frequency(po_mixer *m, double f)
+{
+    m->freq = -f;
+    m->inc = PO_TWOPI * m->freq / m->fs;
+    m->osc_cos = cos(m->inc);
+    m->osc_sin = sin(m->inc);
+    m->last_re = 1.0;
+    m->last_im = 0.0;
+}
+
+/* mixer.cpp:48-81: rotate, amplitude stabiliser 1.95-|last|^2, out = osc*in (cpx.h:203-206) */
+int po_mixer_process(po_mixer *m, const double *in, double *out, uint32_t n)
+{
+    if (m->freq == 0) return 0;
+    for (uint32_t i = 0; i < n; i++) {
+        double ore = m->last_re * m->osc_cos - m->last_im * m->osc_sin;
+        double oim = m->last_re * m->osc_sin + m->last_im * m->osc_cos;
+        double gn = 1.95 - (m->last_re * m->last_re + m->last_im * m->last_im);
+        m->last_re = gn * ore;
+        m->last_im = gn * oim;
+        double xr = in[2 * i], xi = in[2 * i + 1];
+        out[2 * i] = (ore * xr) - (oim * xi);
+        out[2 * i + 1] = (ore * xi) + (oim * xr);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Decimator -- pebblelib/decimator.cpp (vDSP path, m_useVdsp = m_combineStages = true, :9-10)
+ * ---------------------------------------------------------------------------------------------- */
+#define PO_MAX_STAGES 32
+typedef struct {
+    int design;       /* index into pebble_hb_designs */
+    int ntaps;        /* 0 => CIC3 */
+    uint32_t stride;  /* m_decimate */
+    /* halfband history: last ntaps-1 inputs (m_lastXVDsp head), split re/im */
+    double *hist_re, *hist_im;
+    size_t hist_cap;
+    /* CIC3 state m_xOdd / m_xEven */
+    double xodd_re, xodd_im, xeven_re, xeven_im;
+} po_stage;
+
+struct po_decimator {
+    po_stage st[PO_MAX_STAGES];
+    int nst;
+    uint32_t dec_by2;
+    float rate; /* m_decimatedSampleRate is float, decimator.h:251 */
+    /* ping-pong split-complex work buffers (m_splitComplexIn/Out) */
+    double *buf[2][2];
+    size_t buf_cap;
+};
+
+po_decimator *po_decimator_new(void)
+{
+    return (po_decimator *)calloc(1, sizeof(po_decimator));
+}
+
+static void po_decimator_clear(po_decimator *d)
+{
+    for (int i = 0; i < d->nst; i++) {
+        free(d->st[i].hist_re);
+        free(d->st[i].hist_im);
+    }
+    memset(d->st, 0, sizeof(d->st));
+    d->nst = 0;
+}
+
+void po_decimator_free(po_decimator *d)
+{
+    if (!d) return;
+    po_decimator_clear(d);
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) free(d->buf[a][b]);
+    free(d);
+}
+
+/* decimator.cpp:64-149.  The if/else ladder picks the FIRST design (cic3, hb11, hb15, ...) whose
+ * rate >= protectBw / wPass holds; identical consecutive picks double the previous stage's stride
+ * (m_decimate *= 2, :141) instead of adding a stage. */
+double po_decimator_build(po_decimator *d, uint32_t fs_in, uint32_t protect_bw, uint32_t fs_out_min)
+{
+    po_decimator_clear(d);
+    d->rate = (float)fs_in;
+    double protect = (double)protect_bw;
+    uint32_t min_out = fs_out_min > 0 ? fs_out_min : 15000u; /* minDecimatedSampleRate, decimator.h:245 */
+    d->dec_by2 = 0;
+    int prev = -1;
+    while (d->rate > (float)min_out) {
+        int pick = -1;
+        for (int k = 0; k < PEBBLE_HB_NDESIGNS; k++) {
+            if ((double)d->rate >= protect / pebble_hb_designs[k].wpass) { pick = k; break; }
+        }
+        if (pick < 0) break; /* "Ran out of filters before minimum sample rate", :125-127 */
+        d->dec_by2++;
+        if (prev < 0 || d->st[prev].ntaps != pebble_hb_designs[pick].ntaps) {
+            if (d->nst >= PO_MAX_STAGES) break;
+            po_stage *s = &d->st[d->nst];
+            memset(s, 0, sizeof(*s));
+            s->design = pick;
+            s->ntaps = pebble_hb_designs[pick].ntaps;
+            s->stride = 2;
+            prev = d->nst++;
+        } else {
+            d->st[prev].stride *= 2;
+        }
+        d->rate /= 2;
+    }
+    return (double)d->rate;
+}
+
+int po_decimator_chain_len(const po_decimator *d) { return d->nst; }
+uint32_t po_decimator_dec_by2_stages(const po_decimator *d) { return d->dec_by2; }
+void po_decimator_stage(const po_decimator *d, int i, int *ntaps, uint32_t *stride, int *design)
+{
+    if (ntaps) *ntaps = d->st[i].ntaps;
+    if (stride) *stride = d->st[i].stride;
+    if (design) *design = d->st[i].design;
+}
+
+static void po_grow(double **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return;
+    double *q = (double *)calloc(need, sizeof(double));
+    if (*p) { memcpy(q, *p, *cap * sizeof(double)); free(*p); }
+    *p = q;
+    *cap = need;
+}
+
+/* HalfbandFilter::processCIC3, decimator.cpp:719-737 (split-complex twin).  NOTE the merged form:
+ * the loop advances by m_decimate but still only reads in[i], in[i+1]. */
+static uint32_t po_stage_cic3(po_stage *s, const double *xre, const double *xim, double *yre, double *yim, uint32_t n)
+{
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < n; i += s->stride) {
+        double er = xre[i], ei = xim[i], orr = xre[i + 1], oi = xim[i + 1];
+        yre[cnt] = .125 * (orr + s->xeven_re + 3.0 * (s->xodd_re + er));
+        yim[cnt] = .125 * (oi + s->xeven_im + 3.0 * (s->xodd_im + ei));
+        s->xodd_re = orr; s->xodd_im = oi;
+        s->xeven_re = er; s->xeven_im = ei;
+        cnt++;
+    }
+    return cnt;
+}
+
+/* HalfbandFilter::convolveVDsp2, decimator.cpp:593-659.  vDSP_zrdesampD semantics are the
+ * pseudo-code quoted at :637-647: C[n] = sum_p A[n*DF+p]*F[p], summed left to right, all taps
+ * (zeros included).  x_cap = readable length of the x buffers (for the fallback's over-read). */
+static uint32_t po_stage_hb(po_stage *s, const double *xre, const double *xim, size_t x_cap,
+                            double *yre, double *yim, uint32_t n)
+{
+    const double *h = pebble_hb_designs[s->design].h;
+    uint32_t hlen = (uint32_t)s->ntaps, dlen = hlen - 1, dec = s->stride;
+    size_t need = (size_t)dlen + (n > hlen ? n : hlen) + 1;
+    if (s->hist_cap < need) {
+        size_t c1 = s->hist_cap, c2 = s->hist_cap;
+        po_grow(&s->hist_re, &c1, need);
+        po_grow(&s->hist_im, &c2, need);
+        s->hist_cap = need;
+    }
+    if (n < hlen) {
+        /* :603-625 fallback: plain sample dropping, and a history refill that indexes x[i] up to
+         * hLen-1 (past the n valid samples: the reference reads whatever the ping-pong buffer holds;
+         * here that is the stale, initially zero, content of our own ping-pong buffer). */
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < n; i += dec) { yre[cnt] = xre[i]; yim[cnt] = xim[i]; cnt++; }
+        uint32_t save = dlen - n;
+        for (uint32_t i = 0; i < hlen; i++) {
+            if (i < save) { s->hist_re[i] = 0; s->hist_im[i] = 0; }
+            else {
+                s->hist_re[i] = (i < x_cap) ? xre[i] : 0.0;
+                s->hist_im[i] = (i < x_cap) ? xim[i] : 0.0;
+            }
+        }
+        return cnt;
+    }
+    memcpy(s->hist_re + dlen, xre, n * sizeof(double));
+    memcpy(s->hist_im + dlen, xim, n * sizeof(double));
+    uint32_t ylen = n / dec;
+    for (uint32_t k = 0; k < ylen; k++) {
+        double sr = 0, si = 0;
+        const double *ar = s->hist_re + (size_t)k * dec, *ai = s->hist_im + (size_t)k * dec;
+        for (uint32_t p = 0; p < hlen; p++) { sr += ar[p] * h[p]; si += ai[p] * h[p]; }
+        yre[k] = sr; yim[k] = si;
+    }
+    memmove(s->hist_re, xre + (n - dlen), dlen * sizeof(double));
+    memmove(s->hist_im, xim + (n - dlen), dlen * sizeof(double));
+    return ylen;
+}
+
+/* Decimator::process, decimator.cpp:152-226 (vDSP branch): split, run the chain ping-pong, join.
+ * The reference's scratch is capped at maxResultLen=32768 (decimator.h:193); here buffers grow. */
+uint32_t po_decimator_process(po_decimator *d, const double *in, double *out, uint32_t n)
+{
+    if (d->nst == 0) { memcpy(out, in, (size_t)n * 2 * sizeof(double)); return n; }
+    size_t need = (size_t)n * 2 + 64;
+    if (d->buf_cap < need) {
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) { size_t c = d->buf_cap; po_grow(&d->buf[a][b], &c, need); }
+        d->buf_cap = need;
+    }
+    for (uint32_t i = 0; i < n; i++) { d->buf[0][0][i] = in[2 * i]; d->buf[0][1][i] = in[2 * i + 1]; }
+    int cur = 0;
+    uint32_t rem = n;
+    for (int i = 0; i < d->nst; i++) {
+        po_stage *s = &d->st[i];
+        if (s->ntaps == 0) rem = po_stage_cic3(s, d->buf[cur][0], d->buf[cur][1], d->buf[cur ^ 1][0], d->buf[cur ^ 1][1], rem);
+        else rem = po_stage_hb(s, d->buf[cur][0], d->buf[cur][1], d->buf_cap, d->buf[cur ^ 1][0], d->buf[cur ^ 1][1], rem);
+        cur ^= 1;
+    }
+    for (uint32_t i = 0; i < rem; i++) { out[2 * i] = d->buf[cur][0][i]; out[2 * i + 1] = d->buf[cur][1][i]; }
+    return rem;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FFT -- the reference's default back end is Apple vDSP_fft_ziptD (closed source, absent here):
+ * fftaccelerate.cpp:42-105.  Its published contract is the standard unnormalised DFT (forward
+ * e^{-j2pi nk/N}, inverse e^{+j}); restated as an iterative radix-2 with fp64 twiddles from sin/cos.
+ * ---------------------------------------------------------------------------------------------- */
+void po_fft(double *x, uint32_t n, int dir)
+{
+    /* bit reversal */
+    for (uint32_t i = 1, j = 0; i < n; i++) {
+        uint32_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double tr = x[2 * i], ti = x[2 * i + 1];
+            x[2 * i] = x[2 * j]; x[2 * i + 1] = x[2 * j + 1];
+            x[2 * j] = tr; x[2 * j + 1] = ti;
+        }
+    }
+    double sgn = dir >= 0 ? -1.0 : 1.0;
+    for (uint32_t len = 2; len <= n; len <<= 1) {
+        uint32_t half = len >> 1;
+        for (uint32_t k = 0; k < half; k++) {
+            double ang = sgn * PO_TWOPI * (double)k / (double)len;
+            double wr = cos(ang), wi = sin(ang);
+            for (uint32_t s = k; s < n; s += len) {
+                uint32_t a = s, b = s + half;
+                double br = x[2 * b] * wr - x[2 * b + 1] * wi;
+                double bi = x[2 * b] * wi + x[2 * b + 1] * wr;
+                x[2 * b] = x[2 * a] - br; x[2 * b + 1] = x[2 * a + 1] - bi;
+                x[2 * a] += br; x[2 * a + 1] += bi;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CFastFIR -- pebblelib/fastfir.cpp
+ * ---------------------------------------------------------------------------------------------- */
+struct po_fastfir {
+    uint32_t fft_size, fir_size;
+    double *window;   /* m_pWindowTbl */
+    double *coef;     /* m_pFilterCoef (freq domain after setup) */
+    double *fftbuf;   /* m_pFFTBuf */
+    double *overlap;  /* m_pFFTOverlapBuf */
+    int inpos;        /* m_InBufInPos */
+    double lo, hi, offset, fs;
+};
+
+/* fastfir.cpp:77-145: Blackman-Nuttall window table, zeroed buffers, m_InBufInPos = FIR-1 */
+po_fastfir *po_fastfir_new(uint32_t fft_size, uint32_t fir_size)
+{
+    po_fastfir *f = (po_fastfir *)calloc(1, sizeof(*f));
+    f->fft_size = fft_size; f->fir_size = fir_size;
+    f->window = (double *)calloc(fir_size, sizeof(double));
+    f->coef = (double *)calloc((size_t)fft_size * 2, sizeof(double));
+    f->fftbuf = (double *)calloc((size_t)fft_size * 2, sizeof(double));
+    f->overlap = (double *)calloc((size_t)fir_size * 2, sizeof(double));
+    f->inpos = (int)fir_size - 1;
+    for (uint32_t i = 0; i < fir_size; i++) {
+        f->window[i] = (0.3635819
+                        - 0.4891775 * cos((PO_TWOPI * i) / (fir_size - 1))
+                        + 0.1365995 * cos((2.0 * PO_TWOPI * i) / (fir_size - 1))
+                        - 0.0106411 * cos((3.0 * PO_TWOPI * i) / (fir_size - 1)));
+    }
+    f->lo = -1.0; f->hi = 1.0; f->offset = 1.0; f->fs = 1.0; /* :141-144 */
+    return f;
+}
+
+void po_fastfir_free(po_fastfir *f)
+{
+    if (!f) return;
+    free(f->window); free(f->coef); free(f->fftbuf); free(f->overlap); free(f);
+}
+
+/* fastfir.cpp:191-272 */
+int po_fastfir_setup(po_fastfir *f, double lo, double hi, double offset, double fs)
+{
+    if (lo == f->lo && hi == f->hi && offset == f->offset && fs == f->fs) return 0;
+    f->lo = lo; f->hi = hi; f->offset = offset; f->fs = fs;
+    lo += offset; hi += offset;
+    if ((lo >= hi) || (lo >= fs / 2.0) || (lo <= -fs / 2.0) || (hi >= fs / 2.0) || (hi <= -fs / 2.0))
+        return -1; /* "Filter Parameter error": previous taps stay active */
+    double nFL = lo / fs, nFH = hi / fs;
+    double nFc = (nFH - nFL) / 2.0;
+    double nFs = PO_TWOPI * (nFH + nFL) / 2.0;
+    double fCenter = 0.5 * (double)(f->fir_size - 1);
+    memset(f->coef, 0, (size_t)f->fft_size * 2 * sizeof(double));
+    for (uint32_t i = 0; i < f->fir_size; i++) {
+        double x = (double)i - fCenter, z;
+        if ((double)i == fCenter) z = 2.0 * nFc;
+        else z = sin(PO_TWOPI * x * nFc) / (PO_PI * x) * f->window[i];
+        f->coef[2 * i] = z * cos(nFs * x) / (double)f->fft_size;
+        f->coef[2 * i + 1] = z * sin(nFs * x) / (double)f->fft_size;
+    }
+    po_fft(f->coef, f->fft_size, +1);
+    return 0;
+}
+
+const double *po_fastfir_coef(const po_fastfir *f) { return f->coef; }
+
+/* fastfir.cpp:281-334: sample-at-a-time overlap-save exactly as written */
+int po_fastfir_process(po_fastfir *f, int n, const double *in, double *out)
+{
+    int i = 0, outpos = 0, len = n;
+    int N = (int)f->fft_size, T = (int)f->fir_size;
+    if (!n) return 0;
+    while (len--) {
+        int j = f->inpos - (N - T + 1);
+        if (j >= 0) { f->overlap[2 * j] = in[2 * i]; f->overlap[2 * j + 1] = in[2 * i + 1]; }
+        f->fftbuf[2 * f->inpos] = in[2 * i]; f->fftbuf[2 * f->inpos + 1] = in[2 * i + 1];
+        f->inpos++; i++;
+        if (f->inpos >= N) {
+            po_fft(f->fftbuf, f->fft_size, +1);
+            for (int k = 0; k < N; k++) { /* CpxMpy :325-334 */
+                double sr = f->fftbuf[2 * k], si = f->fftbuf[2 * k + 1];
+                double mr = f->coef[2 * k], mi = f->coef[2 * k + 1];
+                f->fftbuf[2 * k] = mr * sr - mi * si;
+                f->fftbuf[2 * k + 1] = mr * si + mi * sr;
+            }
+            po_fft(f->fftbuf, f->fft_size, -1);
+            for (j = T - 1; j < N; j++) { out[2 * outpos] = f->fftbuf[2 * j]; out[2 * outpos + 1] = f->fftbuf[2 * j + 1]; outpos++; }
+            for (j = 0; j < T - 1; j++) { f->fftbuf[2 * j] = f->overlap[2 * j]; f->fftbuf[2 * j + 1] = f->overlap[2 * j + 1]; }
+            f->inpos = T - 1;
+        }
+    }
+    return outpos;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectrum -- pebblelib/fft.cpp + windowfunction.cpp + db.h
+ * ---------------------------------------------------------------------------------------------- */
+struct po_spectrum {
+    uint32_t fft_size, spb;
+    int window_type;
+    double *window;      /* WindowFunction::window */
+    double coherent_gain;
+    double max_bin_power;
+    double *time, *freq; /* m_timeDomain / unfolded */
+    double *prev_power, *prev_amp; /* m_fftPower / m_fftAmplitude (zero-initialised here; the
+                                      reference leaves them uninitialised, fft.cpp:107-115) */
+};
+
+po_spectrum *po_spectrum_new(uint32_t fft_size, uint32_t samples_per_buffer, int window_type, int lift_clamp)
+{
+    po_spectrum *s = (po_spectrum *)calloc(1, sizeof(*s));
+    /* fft.cpp:72-79 clamp to [2048, 65535] */
+    if (fft_size < 2048) fft_size = 2048;
+    else if (fft_size > 65535 && !lift_clamp) fft_size = 65535;
+    s->fft_size = fft_size; s->spb = samples_per_buffer; s->window_type = window_type;
+    s->max_bin_power = 1.0 * samples_per_buffer; /* m_ampMax * m_samplesPerBuffer, fft.cpp:84 */
+    s->window = (double *)calloc(samples_per_buffer, sizeof(double));
+    s->time = (double *)calloc((size_t)fft_size * 2, sizeof(double));
+    s->freq = (double *)calloc((size_t)fft_size * 2, sizeof(double));
+    s->prev_power = (double *)calloc(fft_size, sizeof(double));
+    s->prev_amp = (double *)calloc(fft_size, sizeof(double));
+    if (window_type == 0) {
+        /* windowfunction.cpp:49-51,214-235: float two_pi and float a0..a3, (i+0.5)/N phase */
+        float two_pi = (float)PO_TWOPI;
+        float a0 = 0.35875F, a1 = 0.48829F, a2 = 0.14128F, a3 = 0.01168F;
+        double sum = 0;
+        int N = (int)samples_per_buffer;
+        for (int i = 0; i < N; i++) {
+            s->window[i] = a0 - a1 * cos(two_pi * (i + 0.5) / N)
+                           + a2 * cos(2.0 * two_pi * (i + 0.5) / N)
+                           - a3 * cos(3.0 * two_pi * (i + 0.5) / N);
+            sum += s->window[i];
+        }
+        s->coherent_gain = sum / N;
+    } else {
+        s->coherent_gain = 1.0; /* NONE: regenerate() leaves it untouched; not used on our paths */
+    }
+    return s;
+}
+
+void po_spectrum_free(po_spectrum *s)
+{
+    if (!s) return;
+    free(s->window); free(s->time); free(s->freq); free(s->prev_power); free(s->prev_amp); free(s);
+}
+uint32_t po_spectrum_bins(const po_spectrum *s) { return s->fft_size; }
+double po_spectrum_coherent_gain(const po_spectrum *s) { return s->coherent_gain; }
+const double *po_spectrum_window(const po_spectrum *s) { return s->window; }
+
+static double po_clip_db(double db) { return db < -120.0 ? -120.0 : (db > 0.0 ? 0.0 : db); } /* db.h:24-26 */
+
+/* FFTAccelerate::fftSpectrum, fftaccelerate.cpp:106-119 -> m_applyWindow (fft.cpp:129-157),
+ * forward FFT, m_unfoldInOrder (fft.cpp:207-213), calcPowerAverages (fft.cpp:324-399). */
+int po_spectrum_process(po_spectrum *s, const double *in, uint32_t n, double *out_db)
+{
+    int overload = 0;
+    uint32_t N = s->fft_size;
+    if (s->window_type == 0 && n == s->spb) {
+        for (uint32_t i = 0; i < s->spb; i++) {
+            if (fabs(in[2 * i]) > 0.9 || fabs(in[2 * i + 1]) > 0.9) overload = 1;
+            /* in[i] * windowCpx[i] with windowCpx = (w, 0): full complex product */
+            double w = s->window[i];
+            s->time[2 * i] = in[2 * i] * w - in[2 * i + 1] * 0.0;
+            s->time[2 * i + 1] = in[2 * i] * 0.0 + in[2 * i + 1] * w;
+        }
+        for (uint32_t i = s->spb; i < N; i++) { s->time[2 * i] = 0; s->time[2 * i + 1] = 0; }
+    } else {
+        memset(s->time, 0, (size_t)N * 2 * sizeof(double));
+        memcpy(s->time, in, (size_t)(n < N ? n : N) * 2 * sizeof(double));
+    }
+    po_fft(s->time, N, +1);
+    uint32_t mid = N / 2;
+    memcpy(s->freq + 2 * (size_t)mid, s->time, (size_t)mid * 2 * sizeof(double));
+    memcpy(s->freq, s->time + 2 * (size_t)mid, (size_t)(N - mid) * 2 * sizeof(double));
+    for (uint32_t i = 0; i < N; i++) {
+        double re = s->freq[2 * i], im = s->freq[2 * i + 1];
+        double asd = sqrt(re * re + im * im) / s->coherent_gain; /* DB::amplitude, db.h:28-30 */
+        double psd = asd * asd;                                  /* amplitudeToPower, db.h:90-92 */
+        psd /= s->max_bin_power;
+        asd /= s->max_bin_power;
+        double bin_amp = (asd + s->prev_amp[i]) / 2;             /* m_isAveraged = true, fft.cpp:101 */
+        s->prev_power[i] = psd;
+        s->prev_amp[i] = asd;
+        double db = (bin_amp == 0) ? -120.0 : 20 * log10(bin_amp); /* amplitudeTodB, db.h:44-48 */
+        out_db[i] = po_clip_db(db);
+    }
+    return overload;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CFir -- pebblelib/fir.cpp
+ * ---------------------------------------------------------------------------------------------- */
+static double po_izero(double x) /* fir.cpp:494-512 */
+{
+    double x2 = x / 2.0, sum = 1.0, ds = 1.0, di = 1.0, tmp;
+    do {
+        tmp = x2 / di;
+        tmp *= tmp;
+        ds *= tmp;
+        sum += ds;
+        di += 1.0;
+    } while (ds >= 1e-9 * sum);
+    return sum;
+}
+
+/* CFir::InitLPFilter, fir.cpp:246-337 (MAX_NUMCOEF = 75, filtercoef.h) */
+int po_fir_init_lp(po_fir *f, int ntaps, double scale, double astop, double fpass, double fstop, double fs)
+{
+    double nfp = fpass / fs, nfs = fstop / fs, nfc = (nfs + nfp) / 2.0, beta;
+    if (astop < 20.96) beta = 0;
+    else if (astop >= 50.0) beta = .1102 * (astop - 8.71);
+    else beta = .5842 * pow((astop - 20.96), 0.4) + .07886 * (astop - 20.96);
+    f->ntaps = (int)((astop - 8.0) / (2.285 * PO_TWOPI * (nfs - nfp)) + 1);
+    if (f->ntaps > 75) f->ntaps = 75;
+    if (f->ntaps < 3) f->ntaps = 3;
+    if (ntaps) f->ntaps = ntaps;
+    double fCenter = .5 * (double)(f->ntaps - 1);
+    double izb = po_izero(beta);
+    for (int n = 0; n < f->ntaps; n++) {
+        double x = (double)n - fCenter, c;
+        if ((double)n == fCenter) c = 2.0 * nfc;
+        else c = sin(PO_TWOPI * x * nfc) / (PO_PI * x);
+        x = ((double)n - ((double)f->ntaps - 1.0) / 2.0) / (((double)f->ntaps - 1.0) / 2.0);
+        f->coef[n] = scale * c * po_izero(beta * sqrt(1 - (x * x))) / izb;
+    }
+    for (int n = 0; n < f->ntaps; n++) f->coef[n + f->ntaps] = f->coef[n];
+    for (int i = 0; i < f->ntaps; i++) { f->zre[i] = 0; f->zim[i] = 0; }
+    f->state = 0;
+    return f->ntaps;
+}
+
+/* CFir::ProcessFilter (complex), fir.cpp:106-132: circular delay line, summation in slot order */
+void po_fir_process_cpx(po_fir *f, int n, const double *in, double *out)
+{
+    for (int i = 0; i < n; i++) {
+        f->zre[f->state] = in[2 * i];
+        f->zim[f->state] = in[2 * i + 1];
+        const double *h = f->coef + f->ntaps - f->state;
+        double ar = h[0] * f->zre[0], ai = h[0] * f->zim[0];
+        for (int j = 1; j < f->ntaps; j++) { ar += h[j] * f->zre[j]; ai += h[j] * f->zim[j]; }
+        if (--f->state < 0) f->state += f->ntaps;
+        out[2 * i] = ar; out[2 * i + 1] = ai;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CIir -- pebblelib/iir.cpp (RBJ biquads, direct form 2)
+ * ---------------------------------------------------------------------------------------------- */
+static void po_iir_common(po_iir *q, double f0, double Q, double fs, double *w0, double *alpha, double *A)
+{
+    *w0 = PO_TWOPI * f0 / fs;
+    *alpha = sin(*w0) / (2.0 * Q);
+    *A = 1.0 / (1.0 + *alpha);
+    q->a1 = *A * (-2.0 * cos(*w0));
+    q->a2 = *A * (1.0 - *alpha);
+    q->w1a = q->w2a = q->w1b = q->w2b = 0.0;
+}
+void po_iir_init_lp(po_iir *q, double f0, double Q, double fs) /* iir.cpp:88-103 */
+{
+    double w0, al, A; po_iir_common(q, f0, Q, fs, &w0, &al, &A);
+    q->b0 = A * ((1.0 - cos(w0)) / 2.0); q->b1 = A * (1.0 - cos(w0)); q->b2 = A * ((1.0 - cos(w0)) / 2.0);
+}
+void po_iir_init_hp(po_iir *q, double f0, double Q, double fs) /* iir.cpp:110-125 */
+{
+    double w0, al, A; po_iir_common(q, f0, Q, fs, &w0, &al, &A);
+    q->b0 = A * ((1.0 + cos(w0)) / 2.0); q->b1 = -A * (1.0 + cos(w0)); q->b2 = A * ((1.0 + cos(w0)) / 2.0);
+}
+void po_iir_init_bp(po_iir *q, double f0, double Q, double fs) /* iir.cpp:131-146 */
+{
+    double w0, al, A; po_iir_common(q, f0, Q, fs, &w0, &al, &A);
+    q->b0 = A * al; q->b1 = 0.0; q->b2 = A * -al;
+}
+void po_iir_init_br(po_iir *q, double f0, double Q, double fs) /* iir.cpp:152-167 */
+{
+    double w0, al, A; po_iir_common(q, f0, Q, fs, &w0, &al, &A);
+    q->b0 = A * 1.0; q->b1 = A * (-2.0 * cos(w0)); q->b2 = A * 1.0;
+}
+void po_iir_process_cpx(po_iir *q, int n, const double *in, double *out) /* iir.cpp:191-207 */
+{
+    for (int i = 0; i < n; i++) {
+        double w0a = in[2 * i] - q->a1 * q->w1a - q->a2 * q->w2a;
+        out[2 * i] = q->b0 * w0a + q->b1 * q->w1a + q->b2 * q->w2a;
+        q->w2a = q->w1a; q->w1a = w0a;
+        double w0b = in[2 * i + 1] - q->a1 * q->w1b - q->a2 * q->w2b;
+        out[2 * i + 1] = q->b0 * w0b + q->b1 * q->w1b + q->b2 * q->w2b;
+        q->w2b = q->w1b; q->w1b = w0b;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * AM demod -- application/demod/demod_am.cpp
+ * ---------------------------------------------------------------------------------------------- */
+void po_demod_am_init(po_demod_am *d, double fs)
+{
+    memset(d, 0, sizeof(*d));
+    d->fs = fs;
+    po_demod_am_set_bandwidth(d, 16000); /* ctor, demod_am.cpp:9 */
+}
+void po_demod_am_set_bandwidth(po_demod_am *d, double bw) /* demod_am.cpp:17-21 */
+{
+    po_fir_init_lp(&d->lp, 0, 1.0, 50.0, bw, bw * 1.8, d->fs);
+}
+void po_demod_am_process(po_demod_am *d, const double *in, double *out, int n) /* demod_am.cpp:40-64 */
+{
+    for (int i = 0; i < n; i++) {
+        double mag = sqrt(in[2 * i] * in[2 * i] + in[2 * i + 1] * in[2 * i + 1]);
+        d->dc = (0.9999f * d->dc_last) + mag; /* DC_ALPHA is a float literal, :36 */
+        double am = d->dc - d->dc_last;
+        d->dc_last = d->dc;
+        out[2 * i] = am; out[2 * i + 1] = am;
+    }
+    po_fir_process_cpx(&d->lp, n, out, out);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * WFM mono demod -- application/demod/demod_wfm.cpp
+ * ---------------------------------------------------------------------------------------------- */
+void po_demod_wfm_init(po_demod_wfm *d, double fs) /* init()+setSampleRate(), demod_wfm.cpp:100-196 */
+{
+    memset(d, 0, sizeof(*d));
+    d->fs = fs;
+    po_iir_init_lp(&d->mono_lp, 75000, 1.0, fs);                     /* :164 */
+    po_fir_init_lp(&d->lp, 0, 1.0, 60.0, 15000.0, 1.4 * 15000.0, fs); /* :175 (m_OutRate == rate) */
+    po_iir_init_br(&d->notch, 19000.0, 5, fs);                        /* :178 */
+    d->deemph_alpha = (1.0 - exp(-1.0 / (fs * 75E-6)));               /* :181-183, 451-457 */
+}
+void po_demod_wfm_process_mono(po_demod_wfm *d, const double *in, double *out, int n) /* :207-232 */
+{
+    double *tmp = (double *)malloc((size_t)n * 2 * sizeof(double));
+    if (d->fs >= 150000) po_iir_process_cpx(&d->mono_lp, n, in, tmp);
+    else memcpy(tmp, in, (size_t)n * 2 * sizeof(double));
+    for (int i = 0; i < n; i++) {
+        double d0r = tmp[2 * i], d0i = tmp[2 * i + 1];
+        double v = 0.25 * atan2((d->d1_re * d0i - d0r * d->d1_im), (d->d1_re * d0r + d->d1_im * d0i));
+        out[2 * i] = v; out[2 * i + 1] = v;
+        d->d1_re = d0r; d->d1_im = d0i;
+    }
+    free(tmp);
+    po_fir_process_cpx(&d->lp, n, out, out);
+    for (int i = 0; i < n; i++) { /* processDeemphasisFilter (complex), :476-485 */
+        d->deemph_re = (1.0 - d->deemph_alpha) * d->deemph_re + d->deemph_alpha * out[2 * i];
+        d->deemph_im = (1.0 - d->deemph_alpha) * d->deemph_im + d->deemph_alpha * out[2 * i + 1];
+        out[2 * i] = d->deemph_re * 2.0; out[2 * i + 1] = d->deemph_im * 2.0;
+    }
+    po_iir_process_cpx(&d->notch, n, out, out);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Receiver::processIQData skeleton -- application/receiver.cpp
+ * ---------------------------------------------------------------------------------------------- */
+struct po_receiver {
+    uint32_t fs, n;
+    int mode;
+    po_mixer mixer;
+    po_decimator *dec, *dec_wfm;
+    int demod_rate, wfm_rate; /* int members, receiver.h:165-166: fractional rates truncate */
+    po_spectrum *spec;
+    po_fastfir *bp;
+    po_demod_am am;
+    po_demod_wfm wfm;
+    double *mixed, *working, *samplebuf, *bpout, *demodout;
+    uint32_t samplebuf_len;
+};
+
+po_receiver *po_receiver_new(uint32_t fs, uint32_t n, uint32_t spectrum_bins, uint32_t fastfir_fft, uint32_t fastfir_taps)
+{
+    po_receiver *r = (po_receiver *)calloc(1, sizeof(*r));
+    r->fs = fs; r->n = n; r->mode = PO_AM;
+    po_mixer_init(&r->mixer, (double)fs);                                /* receiver.cpp:156 */
+    r->dec = po_decimator_new();
+    r->demod_rate = (int)po_decimator_build(r->dec, fs, 30000, 0);       /* :194-195 */
+    r->dec_wfm = po_decimator_new();
+    r->wfm_rate = (int)po_decimator_build(r->dec_wfm, fs, 200000, 0);    /* :212-213 */
+    if (spectrum_bins) r->spec = po_spectrum_new(spectrum_bins, n, 0, 0); /* :221, signalspectrum.cpp:58 */
+    r->bp = po_fastfir_new(fastfir_fft ? fastfir_fft : 2048, fastfir_taps ? fastfir_taps : 1025); /* :261 */
+    po_demod_am_init(&r->am, (double)r->demod_rate);                     /* :228, demod.cpp:62 */
+    po_demod_wfm_init(&r->wfm, (double)r->wfm_rate);                     /* demod.cpp:65 */
+    r->mixed = (double *)calloc((size_t)n * 2, sizeof(double));
+    r->working = (double *)calloc((size_t)n * 2, sizeof(double));
+    r->samplebuf = (double *)calloc((size_t)n * 2, sizeof(double));
+    r->bpout = (double *)calloc((size_t)n * 2 + 2 * (size_t)(fastfir_fft ? fastfir_fft : 2048), sizeof(double));
+    r->demodout = (double *)calloc((size_t)n * 2, sizeof(double));
+    return r;
+}
+
+void po_receiver_free(po_receiver *r)
+{
+    if (!r) return;
+    po_decimator_free(r->dec); po_decimator_free(r->dec_wfm);
+    po_spectrum_free(r->spec); po_fastfir_free(r->bp);
+    free(r->mixed); free(r->working); free(r->samplebuf); free(r->bpout); free(r->demodout);
+    free(r);
+}
+
+void po_receiver_set_mode(po_receiver *r, int mode) { r->mode = mode; r->samplebuf_len = 0; } /* :640-655 */
+void po_receiver_set_mixer(po_receiver *r, double f) { po_mixer_set_frequency(&r->mixer, f); } /* :709-716 */
+int po_receiver_set_filter(po_receiver *r, double lo, double hi) /* :658-664, bandpassfilter.cpp:38-46 */
+{
+    int rc = po_fastfir_setup(r->bp, (float)lo, (float)hi, 0, (double)(uint32_t)r->demod_rate);
+    if (r->mode == PO_AM) po_demod_am_set_bandwidth(&r->am, hi - lo); /* demod.cpp:230-239 */
+    return rc;
+}
+double po_receiver_demod_rate(const po_receiver *r, int wfm) { return wfm ? r->wfm_rate : r->demod_rate; }
+uint32_t po_receiver_dec_stages(const po_receiver *r, int wfm)
+{
+    return po_decimator_dec_by2_stages(wfm ? r->dec_wfm : r->dec);
+}
+
+uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, double *audio, double *spectrum_db)
+{
+    /* :826 SignalSpectrum::unprocessed (timer gate forced open: every frame) */
+    if (r->spec && spectrum_db) po_spectrum_process(r->spec, in, n, spectrum_db);
+    const double *next = in;
+    if (po_mixer_process(&r->mixer, in, r->mixed, n)) next = r->mixed; /* :867 / :910 */
+    int wfm = (r->mode == PO_FMM || r->mode == PO_FMS);
+    uint32_t cnt = po_decimator_process(wfm ? r->dec_wfm : r->dec, next, r->working, n); /* :868 / :911 */
+    for (uint32_t i = 0; i < cnt; i++) { /* :873-875 / :922-924 */
+        if (r->samplebuf_len < r->n) {
+            r->samplebuf[2 * r->samplebuf_len] = r->working[2 * i];
+            r->samplebuf[2 * r->samplebuf_len + 1] = r->working[2 * i + 1];
+        }
+        r->samplebuf_len++;
+    }
+    if (r->samplebuf_len < r->n) return 0; /* :878-879 / :927-928 */
+    uint32_t ns = r->n;
+    r->samplebuf_len = 0;
+    if (wfm) {
+        /* :896 Demod::processBlock -> fmMono (stereo is out of scope: SURVEY 8(f) rank 4) */
+        po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns);
+        return ns;
+    }
+    /* :935-938 gain restore 10^(2*stages/20) */
+    double g = pow(10, (double)(po_decimator_dec_by2_stages(r->dec) * 2) / 20.0);
+    for (uint32_t i = 0; i < 2 * ns; i++) r->samplebuf[i] = r->samplebuf[i] * g;
+    /* :950 band-pass.  With the stock 2048/1025 sizes and n=2048 this returns exactly n samples per
+     * call; the parametrised 8192/4097 variant returns 0 or 4096 alternately, and the chain below then
+     * runs on however many samples came out (the stock BandPassFilter::process ignores the count,
+     * bandpassfilter.cpp:53-56, which only works for the stock sizes). */
+    int nb = po_fastfir_process(r->bp, (int)ns, r->samplebuf, r->bpout);
+    if (nb <= 0) return 0;
+    if (r->mode == PO_NONE) { memset(audio, 0, (size_t)nb * 2 * sizeof(double)); return (uint32_t)nb; } /* :968-971 */
+    /* :987 demod (AGC/ANF identity, see header) */
+    if (r->mode == PO_AM) po_demod_am_process(&r->am, r->bpout, audio, nb);
+    else memcpy(audio, r->bpout, (size_t)nb * 2 * sizeof(double)); /* SSB/CW/DIG/DSB pass-through, demod.cpp:127-138 */
+    return (uint32_t)nb;
+}

@@ -1,0 +1,135 @@
+/*
+ * pebble_oracle.h -- CPU restatement (fp64, scalar C) of PebbleSDR's per-frame IQ receive chain.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP path is compared against, and the
+ * "port" CPU baseline that bench.py times.  Nothing under pebblesdr_amd/ or include/ may include,
+ * link or call it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY PINNING STATUS: the reference (Qt5 + Apple Accelerate, macOS/Windows only) cannot be
+ * built in this image without writing stand-in Qt/vDSP headers, which the build rules forbid, so
+ * there is no oracle/_ref.  The reference ships no tests and no golden vectors.
+ * The oracle is pinned by (1) the one worked known-answer table the reference holds
+ * (pebblelib/fft.cpp:363-369, -10 dB tone -> spectrum peak per FFT size), (2) the outputs of
+ * the reference itself recorded when it was executed at survey time (chain
+ * tables, tap counts, oscillator fixed point, FastFIR pass-band gain, spectrum peaks), and
+ * (3) closed-form / independent-implementation cross-checks (numpy.fft, scipy.signal).  Stages with
+ * none of these say "parity unpinned" in their tests.
+ *
+ * Every function cites the reference file:line it restates (paths relative to /root/reference).
+ * Complex buffers are interleaved (re, im) doubles == CPX = std::complex<double> (pebblelib/cpx.h:96).
+ */
+#ifndef PEBBLE_ORACLE_H
+#define PEBBLE_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- DemodMode numeric values: pebblelib/device_interfaces.h:124-138 ---- */
+enum po_demod_mode { PO_AM = 0, PO_SAM, PO_FMN, PO_FMM, PO_FMS, PO_DSB, PO_LSB, PO_USB, PO_CWL, PO_CWU,
+                     PO_DIGL, PO_DIGU, PO_NONE };
+
+/* ---- Mixer: pebblelib/mixer.cpp:25-81 ---- */
+typedef struct {
+    double fs, freq, inc, osc_cos, osc_sin, last_re, last_im;
+} po_mixer;
+void po_mixer_init(po_mixer *m, double fs);
+void po_mixer_set_frequency(po_mixer *m, double f);                 /* mixer.cpp:25-40 */
+/* returns 1 and fills out[]; returns 0 (out untouched) when frequency==0 (mixer.cpp:51-53: returns in) */
+int po_mixer_process(po_mixer *m, const double *in, double *out, uint32_t n);
+
+/* ---- Decimator: pebblelib/decimator.cpp:64-226, 593-659, 695-753 ---- */
+typedef struct po_decimator po_decimator;
+po_decimator *po_decimator_new(void);
+void po_decimator_free(po_decimator *d);
+/* buildDecimationChain(fs_in, protect_bw, fs_out) -> achieved rate (decimator.cpp:64-149) */
+double po_decimator_build(po_decimator *d, uint32_t fs_in, uint32_t protect_bw, uint32_t fs_out_min);
+int po_decimator_chain_len(const po_decimator *d);
+uint32_t po_decimator_dec_by2_stages(const po_decimator *d);
+/* stage i: ntaps (0 => CIC3), stride (m_decimate after merging), design index into pebble_hb_designs */
+void po_decimator_stage(const po_decimator *d, int i, int *ntaps, uint32_t *stride, int *design);
+/* Decimator::process (vDSP path): returns number of output samples (decimator.cpp:152-226) */
+uint32_t po_decimator_process(po_decimator *d, const double *in, double *out, uint32_t n);
+
+/* ---- plain DFT used by FastFIR and spectrum: Accelerate semantics, fftaccelerate.cpp:42-105 ----
+ * dir=+1 forward e^{-j}, dir=-1 inverse e^{+j}; both unscaled; n power of two; in place. */
+void po_fft(double *x, uint32_t n, int dir);
+
+/* ---- CFastFIR: pebblelib/fastfir.cpp:77-334 (fft_size/fir_size are #defines 2048/1025 there) ---- */
+typedef struct po_fastfir po_fastfir;
+po_fastfir *po_fastfir_new(uint32_t fft_size, uint32_t fir_size);
+void po_fastfir_free(po_fastfir *f);
+/* SetupParameters (fastfir.cpp:191-272): 0 ok / unchanged, -1 "Filter Parameter error" (old taps kept) */
+int po_fastfir_setup(po_fastfir *f, double lo, double hi, double offset, double fs);
+/* ProcessData (fastfir.cpp:281-319): returns samples written to out */
+int po_fastfir_process(po_fastfir *f, int n, const double *in, double *out);
+const double *po_fastfir_coef(const po_fastfir *f);  /* frequency-domain H, fft_size complex */
+
+/* ---- FFT::fftSpectrum: fft.cpp:67-118,129-157,183-225,324-399; windowfunction.cpp:214-235 ---- */
+typedef struct po_spectrum po_spectrum;
+/* window_type: 0 = BLACKMANHARRIS (SignalSpectrum, signalspectrum.cpp:58), 1 = NONE.
+ * lift_clamp!=0 lifts the reference's m_maxFFTSize=65535 clamp (fft.h:21) -- documented deviation. */
+po_spectrum *po_spectrum_new(uint32_t fft_size, uint32_t samples_per_buffer, int window_type, int lift_clamp);
+void po_spectrum_free(po_spectrum *s);
+uint32_t po_spectrum_bins(const po_spectrum *s);
+double po_spectrum_coherent_gain(const po_spectrum *s);
+const double *po_spectrum_window(const po_spectrum *s);
+/* returns overload flag; out has bins doubles (dB amplitude, -f..+f) */
+int po_spectrum_process(po_spectrum *s, const double *in, uint32_t n, double *out_db);
+
+/* ---- CFir: pebblelib/fir.cpp:106-132, 246-337, 494-512 ---- */
+typedef struct {
+    int ntaps, state;
+    double coef[2 * 75];
+    double zre[75], zim[75];
+} po_fir;
+int po_fir_init_lp(po_fir *f, int ntaps, double scale, double astop, double fpass, double fstop, double fs);
+void po_fir_process_cpx(po_fir *f, int n, const double *in, double *out); /* in may == out */
+
+/* ---- CIir: pebblelib/iir.cpp:88-207 ---- */
+typedef struct { double a1, a2, b0, b1, b2, w1a, w2a, w1b, w2b; } po_iir;
+void po_iir_init_lp(po_iir *q, double f0, double Q, double fs);
+void po_iir_init_hp(po_iir *q, double f0, double Q, double fs);
+void po_iir_init_bp(po_iir *q, double f0, double Q, double fs);
+void po_iir_init_br(po_iir *q, double f0, double Q, double fs);
+void po_iir_process_cpx(po_iir *q, int n, const double *in, double *out);
+
+/* ---- Demod_AM::processBlockFiltered: application/demod/demod_am.cpp:17-64 ---- */
+typedef struct { double fs, dc, dc_last; po_fir lp; } po_demod_am;
+void po_demod_am_init(po_demod_am *d, double fs);
+void po_demod_am_set_bandwidth(po_demod_am *d, double bw);
+void po_demod_am_process(po_demod_am *d, const double *in, double *out, int n);
+
+/* ---- Demod_WFM::processDataMono: application/demod/demod_wfm.cpp:154-232, 451-485 ---- */
+typedef struct {
+    double fs, d1_re, d1_im, deemph_alpha, deemph_re, deemph_im;
+    po_iir mono_lp, notch;
+    po_fir lp;
+} po_demod_wfm;
+void po_demod_wfm_init(po_demod_wfm *d, double fs);
+/* in is const here; the reference overwrites its input (demod_wfm.cpp:212) */
+void po_demod_wfm_process_mono(po_demod_wfm *d, const double *in, double *out, int n);
+
+/* ---- Receiver::processIQData, DSP skeleton only: application/receiver.cpp:116-281, 758-1009 ----
+ * Steps that are default-off / identity / GUI are omitted exactly as SURVEY.md 8(a-1) scopes them:
+ * DCRemoval, IQBalance, NoiseBlanker, NoiseFilter, AGC, squelch (forced open), resampler, audio out. */
+typedef struct po_receiver po_receiver;
+po_receiver *po_receiver_new(uint32_t fs, uint32_t frames_per_buffer, uint32_t spectrum_bins,
+                             uint32_t fastfir_fft, uint32_t fastfir_taps);
+void po_receiver_free(po_receiver *r);
+void po_receiver_set_mode(po_receiver *r, int mode);
+void po_receiver_set_mixer(po_receiver *r, double f);                 /* receiver.cpp:709 */
+int po_receiver_set_filter(po_receiver *r, double lo, double hi);     /* receiver.cpp:658 */
+double po_receiver_demod_rate(const po_receiver *r, int wfm);
+uint32_t po_receiver_dec_stages(const po_receiver *r, int wfm);
+/* one frame in; returns number of audio samples written (0 while accumulating, else frames_per_buffer);
+ * spectrum_db (may be NULL) receives the unprocessed spectrum of this frame (every frame, no timer gate).
+ * audio must hold max(frames_per_buffer, fastfir_fft) complex samples (the 8192/4097 FastFIR variant
+ * emits 0 or 4096 samples per call). */
+uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, double *audio, double *spectrum_db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
