@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s through the full receive chain on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): synthetic 20 Msps HackRF-shape IQ, one tuned channel per GPU, mixer ->
+decimator (hb11x8, hb15, hb23, hb47 -> 312.5 kHz) -> WFM mono demod, plus the 8192-bin SignalSpectrum FFT on every
+2048-sample frame.  One "step" = one pass of that chain over one batch of `--superframes` super-frames
+(131072 samples each) already resident in HBM.
+
+  python bench.py [--gpus N --steps K --warmup W]           # N = 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
+
+Channels are independent: every rank owns its own stream, nothing is exchanged, so the only
+collectives are the control-plane barrier and the max-over-ranks of the elapsed time (gloo, CPU tensors) --
+weak scaling.  Rank 0 prints ONE JSON line.
+
+The CPU baseline leg times the oracle (oracle/, a scalar fp64 port of the reference chain) on a bounded sample of
+the same workload; it is the only place this file touches oracle/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FS = 20_000_000
+NF = 2048
+BINS = 8192
+MIX_HZ = 1.0e6
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s is the measured float4-copy ceiling
+
+
+def shard_streams(world, rank, per_rank=1):
+    """Static contiguous shards: rank r owns streams [r*per_rank, (r+1)*per_rank)."""
+    return list(range(rank * per_rank, (rank + 1) * per_rank))
+
+
+def aggregate_msps(samples_per_rank, world, seconds):
+    return samples_per_rank * world / seconds / 1e6
+
+
+def make_input(n, seed):
+    """FM-modulated 1 kHz tone, 75 kHz deviation, +1 MHz offset, noise; quantised to int8/128 (HackRF CPX8 shape)."""
+    from tests.signals import lcg_noise
+    out = np.empty(n, dtype=np.complex64)
+    blk = 1 << 22
+    for lo in range(0, n, blk):
+        hi = min(n, lo + blk)
+        t = np.arange(lo, hi, dtype=np.float64) / FS
+        x = 0.5 * np.exp(1j * (2 * np.pi * MIX_HZ * t + 75.0 * np.sin(2 * np.pi * 1000 * t)))
+        x = x + lcg_noise(hi - lo, seed + lo // blk, 1e-2)
+        out[lo:hi] = (np.round(x.real * 128) + 1j * np.round(x.imag * 128)) / 128.0
+    return out
+
+
+def cpu_baseline(seconds_budget=15.0):
+    """Oracle ("port": scalar fp64 restatement of the reference chain) on this host, 1 thread."""
+    import oracle as O
+    n_frames = 64  # one super-frame at a time
+    x = make_input(n_frames * NF, 99).astype(np.complex128)
+    spec = O.Spectrum(BINS, NF)
+    mix = O.Mixer(FS)
+    mix.set_frequency(MIX_HZ)
+    dec = O.Decimator(FS, 200000)
+    dem = O.DemodWFM(312500)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for f in range(n_frames):
+            spec.process(x[f * NF:(f + 1) * NF])
+        z = np.concatenate([dec.process(mix.process(x[i:i + 8192])) for i in range(0, len(x), 8192)])
+        dem.process(z)
+        done += len(x)
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or done >= 64 * len(x):
+            break
+    return {"value": round(done / el / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d samples (%d super-frames) of the same 20 Msps WFM+spectrum workload, %.1f s, oracle/ scalar fp64" % (done, done // len(x), el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--superframes", type=int, default=256, help="super-frames (131072 samples) per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # control plane only: barrier + max of a CPU scalar (gloo)
+        dist.init_process_group(backend="gloo")
+    assert world == args.gpus or world == 1, "launch one rank per GPU (torch.distributed.run --nproc-per-node N)"
+
+    import pebblesdr_amd as P
+    L = P.load_library()
+    ndev = L.pebblegpu_device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs an MI355X: libpebblegpu has no CPU path")
+    device = local_rank % ndev
+
+    rx = P.ReceiverBank(FS, n_channels=1, shared_input=True, wfm=True, spectrum_bins=BINS,
+                        max_superframes=args.superframes, device=device)
+    rx.set_mixer(0, MIX_HZ)
+    sf = rx.superframe
+    n = args.superframes * sf
+    x = make_input(n, 1000 * (rank + 1))
+    dbuf = P.DeviceBuffer.from_array(P.binding.to_f32_iq(x), device)  # inputs resident in HBM before timing
+    del x
+
+    def barrier():
+        P.binding.check(L, L.pebblegpu_device_synchronize(device))
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rx.process_device(dbuf.ptr, n)
+    rx.synchronize()
+
+    spec_ms, chain_ms = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rx.process_device(dbuf.ptr, n)
+        spec_ms.append(rx.last_ms(1))          # HIP events on the library's stream, around the spectrum kernel
+        chain_ms.append(rx.last_ms(0) - spec_ms[-1])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = n // NF
+        algo_bytes = frames * (8 * NF + 4 * BINS)  # 8*N + 4*bins per frame
+        k_ms = float(np.mean(spec_ms))
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "IQ Msamples/s through full ProcessBlock chain",
+            "value": round(aggregate_msps(n * args.steps, world, elapsed), 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 20 Msps int8-shape IQ, 1 channel/GPU, mixer+decimate(D=64)+WFM mono demod + 8192-bin SignalSpectrum per 2048-sample frame",
+                       "samples_per_step_per_gpu": n, "frames_per_buffer": NF, "spectrum_bins": BINS,
+                       "parallelism": "independent channel per GPU, no collectives"},
+            "roofline": {"bound": "hbm", "kernel": "k_spectrum<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(k_ms, 4),
+                         "rest_of_chain_ms": round(float(np.mean(chain_ms)), 4)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

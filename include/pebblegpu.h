@@ -1,0 +1,198 @@
+/*
+ * pebblegpu.h -- C ABI of libpebblegpu: PebbleSDR's per-frame IQ receive chain on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of the reference: what Receiver::processIQData
+ * (application/receiver.cpp:758-1009) runs between the device plugin's callback and the audio
+ * resampler -- Mixer, Decimator, CFastFIR band-pass, Demod (AM / WFM mono / SSB-CW-DIG pass-through)
+ * and the SignalSpectrum FFT.  Plain pointers and sizes only; no C++/Qt/torch types cross it.
+ * Every entry point names the reference interface it replaces (paths relative to the reference).
+ *
+ * Conventions
+ *   - host complex buffers are interleaved (re, im) doubles == CPX = std::complex<double>
+ *     (pebblelib/cpx.h:96); device complex buffers are interleaved (re, im) floats ("float2").
+ *   - all functions return PEBBLEGPU_OK (0) or a negative pebblegpu_status; nothing throws across
+ *     the ABI; pebblegpu_last_error() returns text for the calling thread's last failure.
+ *   - process_* calls are single-caller per handle (the reference calls processIQData from one
+ *     consumer thread, pebblelib/producerconsumer.cpp:101-109); setters may be called from another
+ *     thread and take effect at the next process call (= frame boundary).
+ *   - the library owns every device buffer it returns; host pointers returned by *_result() stay
+ *     valid until the next process call on the same handle (ProcessStep ownership rule,
+ *     application/processstep.cpp:12-20).  Inputs are never modified (receiver.cpp:747-755).
+ */
+#ifndef PEBBLEGPU_H
+#define PEBBLEGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEBBLEGPU_ABI_VERSION 1
+
+typedef enum {
+    PEBBLEGPU_OK = 0,
+    PEBBLEGPU_E_INVALID = -1,      /* bad argument / bad handle */
+    PEBBLEGPU_E_NO_DEVICE = -2,    /* no HIP device: the library never falls back to the CPU */
+    PEBBLEGPU_E_HIP = -3,          /* HIP runtime error, see pebblegpu_last_error() */
+    PEBBLEGPU_E_FILTER_PARAM = -4, /* CFastFIR "Filter Parameter error": previous taps stay active
+                                      (pebblelib/fastfir.cpp:208-216) */
+    PEBBLEGPU_E_SIZE = -5,         /* sample count not a whole number of super-frames / too large */
+    PEBBLEGPU_E_UNSUPPORTED = -6   /* mode or size outside what this build implements */
+} pebblegpu_status;
+
+/* DeviceInterface::DemodMode numeric values, pebblelib/device_interfaces.h:124-138 (a Qt shim maps 1:1) */
+typedef enum {
+    PEBBLEGPU_DM_AM = 0, PEBBLEGPU_DM_SAM, PEBBLEGPU_DM_FMN, PEBBLEGPU_DM_FMM, PEBBLEGPU_DM_FMS,
+    PEBBLEGPU_DM_DSB, PEBBLEGPU_DM_LSB, PEBBLEGPU_DM_USB, PEBBLEGPU_DM_CWL, PEBBLEGPU_DM_CWU,
+    PEBBLEGPU_DM_DIGL, PEBBLEGPU_DM_DIGU, PEBBLEGPU_DM_NONE
+} pebblegpu_demod_mode;
+
+const char *pebblegpu_last_error(void);
+int pebblegpu_abi_version(void);
+/* number of HIP devices visible (0 => every create() fails with PEBBLEGPU_E_NO_DEVICE) */
+int pebblegpu_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device memory + stream plumbing (so a host needs no other GPU library to feed the chain)
+ * ---------------------------------------------------------------------------------------------- */
+int pebblegpu_malloc(int device, size_t bytes, void **dptr);
+int pebblegpu_free(int device, void *dptr);
+int pebblegpu_memcpy_h2d(int device, void *dst, const void *src, size_t bytes);
+int pebblegpu_memcpy_d2h(int device, void *dst, const void *src, size_t bytes);
+int pebblegpu_memset(int device, void *dst, int value, size_t bytes);
+int pebblegpu_device_synchronize(int device);
+/* normalizeIQ ingest helpers are a "next" row; not part of ABI v1. */
+
+/* ------------------------------------------------------------------------------------------------
+ * Receiver bank: C tuned channels over one shared wideband stream, or C independent streams.
+ * Replaces Receiver::turnPowerOn's step construction (receiver.cpp:154-264) and
+ * Receiver::processIQData's DSP (receiver.cpp:826-987).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pebblegpu_receiver pebblegpu_receiver;
+
+typedef struct {
+    uint32_t struct_size;        /* = sizeof(pebblegpu_config) */
+    int32_t device;              /* HIP device ordinal */
+    double sample_rate;          /* Fs of the device stream, Hz (Key_SampleRate, receiver.cpp:149) */
+    uint32_t frames_per_buffer;  /* reference N: settings.cpp:57 default 2048; spectrum window length */
+    uint32_t n_channels;         /* C */
+    uint32_t shared_input;       /* 1: all channels read stream 0; 0: channel c reads stream c */
+    uint32_t wfm;                /* 0: narrow branch (protect 30 kHz + FastFIR, receiver.cpp:903-993)
+                                    1: WFM branch (protect 200 kHz, no band-pass, receiver.cpp:854-901) */
+    uint32_t spectrum_bins;      /* 0: no spectrum; else FFT size (settings.cpp:59 default 4096) */
+    uint32_t fastfir_fft;        /* 0 -> 2048 (fastfir.cpp:65) */
+    uint32_t fastfir_taps;       /* 0 -> 1025 (fastfir.cpp:66) */
+    uint32_t max_superframes;    /* capacity of one process call, in super-frames (>=1) */
+    uint32_t reserved[5];
+} pebblegpu_config;
+
+int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out);
+int pebblegpu_receiver_destroy(pebblegpu_receiver *rx);
+
+/* What buildDecimationChain (pebblelib/decimator.cpp:64-149) produced for this bank. */
+typedef struct {
+    double demod_rate;           /* achieved rate (float in the reference) */
+    uint32_t demod_rate_int;     /* the int the Receiver stores and designs filters with (receiver.h:165-166) */
+    uint32_t dec_by2_stages;     /* Decimator::decBy2Stages() */
+    uint32_t total_decimation;   /* D */
+    uint32_t chain_len;          /* merged stages */
+    uint32_t stage_taps[16];     /* 0 => CIC3 */
+    uint32_t stage_stride[16];
+    uint64_t superframe;         /* input samples per super-frame = D * frames_per_buffer */
+    uint32_t n_streams;
+    uint32_t spectrum_bins;      /* after the reference's [2048, 65535] clamp (fft.cpp:72-79) */
+} pebblegpu_info;
+int pebblegpu_receiver_info(const pebblegpu_receiver *rx, pebblegpu_info *info);
+
+/* Receiver::mixerChanged -> Mixer::setFrequency (receiver.cpp:709-716, mixer.cpp:25-40): negated
+ * frequency, oscillator phase AND amplitude reset to (1,0). */
+int pebblegpu_set_mixer_freq(pebblegpu_receiver *rx, uint32_t channel, double freq_hz);
+/* Receiver::filterChanged (receiver.cpp:658-664): BandPassFilter::setBandPass -> CFastFIR::SetupParameters
+ * (lo, hi, offset 0, demod rate) and, for AM channels, Demod_AM::setBandwidth(hi - lo). */
+int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_hz, double hi_hz);
+/* Receiver::demodModeChanged -> Demod::setDemodMode (receiver.cpp:640-655).  Narrow banks accept AM and
+ * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM. */
+int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
+
+/* Batched device path.  d_iq: n_streams x n_samples float2 (stream-major, [stream][time]); n_samples must be
+ * k * superframe (k <= max_superframes).  Outputs (library-owned device buffers, valid until the next call):
+ *   audio    [channel][k * frames_per_buffer] float2  (re = left, im = right, receiver.cpp:1029)
+ *   spectrum [stream][n_samples / frames_per_buffer][bins] float, dB amplitude, -f..+f (fft.cpp:395) */
+int pebblegpu_receiver_process(pebblegpu_receiver *rx, const void *d_iq, uint64_t n_samples);
+/* returns channel 0's row; channel c starts *pitch_samples float2 further per channel */
+const void *pebblegpu_receiver_audio(const pebblegpu_receiver *rx, uint64_t *samples_per_channel, uint64_t *pitch_samples);
+const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *frames_per_stream);
+/* Time of the last process call's kernels in ms, from HIP events on the library's stream.  which: 0 whole
+ * call; 1 spectrum kernel; 2 mixer+first-decimator kernel; 3 remaining decimator stages; 4 FastFIR;
+ * 5 demod. */
+int pebblegpu_receiver_last_ms(const pebblegpu_receiver *rx, int which, float *ms);
+int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);
+
+/* Host single-frame path with the reference's callback shape:
+ *   CB_ProcessIQData  = std::function<void(CPX*, quint16)>  (pebblelib/device_interfaces.h:32)
+ *   CB_ProcessAudioData same shape (device_interfaces.h:38).
+ * One frame of n == frames_per_buffer samples for channel/stream 0 in; frames accumulate until a whole
+ * super-frame is present (the reference returns early until m_sampleBuf is full, receiver.cpp:922-931);
+ * then *n_audio = frames_per_buffer (more for FastFIR variants) and audio holds left/right doubles.  Otherwise *n_audio = 0.
+ * spectrum_db (may be NULL) receives this frame's dB spectrum (bins doubles). */
+int pebblegpu_process_iq(pebblegpu_receiver *rx, const double *iq, uint16_t n, double *audio,
+                         uint32_t *n_audio, double *spectrum_db);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone process steps with the reference's per-class call shapes, host buffers in and out.
+ * These back the C++ adapter classes in include/pebblegpu_steps.hpp.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pebblegpu_mixer pebblegpu_mixer;
+/* Mixer::Mixer(sampleRate, bufferSize), mixer.cpp:5-17 */
+int pebblegpu_mixer_create(int device, uint32_t sample_rate, uint32_t buffer_size, pebblegpu_mixer **out);
+int pebblegpu_mixer_destroy(pebblegpu_mixer *m);
+int pebblegpu_mixer_set_frequency(pebblegpu_mixer *m, double f);                 /* mixer.cpp:25-40 */
+/* CPX *Mixer::processBlock(CPX *in), pebblelib/mixer.h:15: *out = library buffer, or = in when f == 0 */
+int pebblegpu_mixer_process(pebblegpu_mixer *m, const double *in, const double **out);
+
+typedef struct pebblegpu_decimator pebblegpu_decimator;
+/* Decimator::Decimator + buildDecimationChain, decimator.cpp:6-46, 64-149 */
+int pebblegpu_decimator_create(int device, uint32_t sample_rate, uint32_t buffer_size, pebblegpu_decimator **out);
+int pebblegpu_decimator_destroy(pebblegpu_decimator *d);
+int pebblegpu_decimator_build_chain(pebblegpu_decimator *d, uint32_t sample_rate_in, uint32_t protect_bw,
+                                    uint32_t sample_rate_out, float *achieved_rate);
+int pebblegpu_decimator_dec_by2_stages(const pebblegpu_decimator *d, uint32_t *stages);
+/* quint32 Decimator::process(CPX *in, CPX *out, quint32 n), pebblelib/decimator.h:238.  Streams with exact
+ * history; a frame shorter than a stage's tap count is NOT degraded to sample dropping (the reference's
+ * fallback, decimator.cpp:602-625, reads indeterminate memory) -- see DESIGN.md section 6. */
+int pebblegpu_decimator_process(pebblegpu_decimator *d, const double *in, double *out, uint32_t n, uint32_t *n_out);
+
+typedef struct pebblegpu_fastfir pebblegpu_fastfir;
+/* CFastFIR::CFastFIR, fastfir.cpp:77-145 (fft/fir sizes are #defines there; 0,0 -> 2048,1025) */
+int pebblegpu_fastfir_create(int device, uint32_t fft_size, uint32_t fir_size, pebblegpu_fastfir **out);
+int pebblegpu_fastfir_destroy(pebblegpu_fastfir *f);
+/* void CFastFIR::SetupParameters(FLoCut, FHiCut, Offset, SampleRate), pebblelib/fastfir.h:57 */
+int pebblegpu_fastfir_setup(pebblegpu_fastfir *f, double lo, double hi, double offset, double sample_rate);
+/* int CFastFIR::ProcessData(int InLength, CPX *in, CPX *out), pebblelib/fastfir.h:59: *n_out samples written */
+int pebblegpu_fastfir_process(pebblegpu_fastfir *f, int n, const double *in, double *out, int *n_out);
+
+typedef struct pebblegpu_demod pebblegpu_demod;
+/* Demod::Demod(sampleRate, wfmSampleRate, bufferSize), application/demod.cpp:49-69 */
+int pebblegpu_demod_create(int device, uint32_t sample_rate, uint32_t wfm_sample_rate, uint32_t buffer_size,
+                           pebblegpu_demod **out);
+int pebblegpu_demod_destroy(pebblegpu_demod *d);
+int pebblegpu_demod_set_mode(pebblegpu_demod *d, int mode);          /* demod.cpp:241-257 */
+int pebblegpu_demod_set_bandwidth(pebblegpu_demod *d, double bw);    /* demod.cpp:230-239 */
+/* CPX *Demod::processBlock(CPX *in, int n), application/demod.h:33: *out = library buffer, or = in for the
+ * pass-through modes (demod.cpp:127-138) */
+int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const double **out);
+
+typedef struct pebblegpu_spectrum pebblegpu_spectrum;
+/* FFT::factory + fftParams(fftSize, 0, sampleRate, samplesPerBuffer, BLACKMANHARRIS), fft.cpp:45-118 */
+int pebblegpu_spectrum_create(int device, uint32_t fft_size, double sample_rate, uint32_t samples_per_buffer,
+                              pebblegpu_spectrum **out);
+int pebblegpu_spectrum_destroy(pebblegpu_spectrum *s);
+int pebblegpu_spectrum_bins(const pebblegpu_spectrum *s, uint32_t *bins);
+/* bool FFT::fftSpectrum(CPX *in, double *out, int numSamples), pebblelib/fft.h:38; *overload = return value */
+int pebblegpu_spectrum_process(pebblegpu_spectrum *s, const double *in, int n, double *out_db, int *overload);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEBBLEGPU_H */

@@ -244,6 +244,19 @@ uint32_t po_decimator_process(po_decimator *d, const double *in, double *out, ui
  * ---------------------------------------------------------------------------------------------- */
 void po_fft(double *x, uint32_t n, int dir)
 {
+    /* twiddle table W_n^k = exp(-2*pi*i*k/n), k < n/2, computed once per size (vDSP_create_fftsetupD does the same) */
+    static uint32_t tab_n = 0;
+    static double *tab = NULL;
+    if (tab_n != n) {
+        free(tab);
+        tab = (double *)malloc((size_t)n * sizeof(double));
+        for (uint32_t k = 0; k < n / 2; k++) {
+            double ang = -PO_TWOPI * (double)k / (double)n;
+            tab[2 * k] = cos(ang);
+            tab[2 * k + 1] = sin(ang);
+        }
+        tab_n = n;
+    }
     /* bit reversal */
     for (uint32_t i = 1, j = 0; i < n; i++) {
         uint32_t bit = n >> 1;
@@ -255,14 +268,13 @@ void po_fft(double *x, uint32_t n, int dir)
             x[2 * j] = tr; x[2 * j + 1] = ti;
         }
     }
-    double sgn = dir >= 0 ? -1.0 : 1.0;
+    double sgn = dir >= 0 ? 1.0 : -1.0;
     for (uint32_t len = 2; len <= n; len <<= 1) {
-        uint32_t half = len >> 1;
-        for (uint32_t k = 0; k < half; k++) {
-            double ang = sgn * PO_TWOPI * (double)k / (double)len;
-            double wr = cos(ang), wi = sin(ang);
-            for (uint32_t s = k; s < n; s += len) {
-                uint32_t a = s, b = s + half;
+        uint32_t half = len >> 1, step = n / len;
+        for (uint32_t s = 0; s < n; s += len) {
+            for (uint32_t k = 0; k < half; k++) {
+                double wr = tab[2 * k * step], wi = sgn * tab[2 * k * step + 1];
+                uint32_t a = s + k, b = s + k + half;
                 double br = x[2 * b] * wr - x[2 * b + 1] * wi;
                 double bi = x[2 * b] * wi + x[2 * b + 1] * wr;
                 x[2 * b] = x[2 * a] - br; x[2 * b + 1] = x[2 * a + 1] - bi;

@@ -1,0 +1,57 @@
+// common.h -- shared definitions for libpebblegpu (gfx950 only; no CPU path, no other GPU back end).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace pg {
+
+constexpr int kWave = 64;           // CDNA wavefront
+constexpr int kBlock = 256;         // default workgroup: 4 waves, one per SIMD
+constexpr int kMaxTaps = 80;        // >= 75 (CFir MAX_NUMCOEF) and >= 59 (largest halfband)
+constexpr int kAmpTab = 512;        // oscillator amplitude transient table length (decays as 0.9^n)
+constexpr int kMaxStages = 16;
+
+// error plumbing: thread-local message, negative status codes (include/pebblegpu.h)
+std::string &last_error();
+int fail(int code, const char *fmt, ...);
+
+#define PG_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return pg::fail(-3, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// kernel launch through a function pointer: the name may be a template-id with commas
+template <class... KA, class... A>
+inline void launch(void (*kernel)(KA...), dim3 grid, dim3 block, hipStream_t stream, A... args)
+{
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, static_cast<KA>(args)...);
+}
+
+// ---- small complex helpers on float2 ----
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b)  // a * conj(b)
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// e^{j 2 pi c}, c in cycles (fp64), reduced to [-0.5, 0.5) before the fp32 sincos
+__device__ __forceinline__ float2 cis_cycles(double c)
+{
+    c -= rint(c);
+    float s, co;
+    sincospif(2.0f * (float)c, &s, &co);
+    return make_float2(co, s);
+}
+
+}  // namespace pg

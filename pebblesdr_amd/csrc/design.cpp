@@ -1,0 +1,189 @@
+// design.cpp -- host-side fp64 filter/chain design (see design.h).
+#include "design.h"
+#include <cmath>
+#include "hb_taps.inc"
+
+namespace pg {
+namespace design {
+
+// The reference's ladder tries cic3, hb11, hb15 ... hb59 in that order and takes the first whose
+// wPass protects the signal at the current rate; a repeat of the previous pick widens that stage's
+// stride instead of adding a stage (pebblelib/decimator.cpp:74-146).
+Chain build_chain(uint32_t fs_in, uint32_t protect_bw, uint32_t fs_out_min)
+{
+    Chain c;
+    c.rate = (float)fs_in;
+    const float floor_rate = (float)(fs_out_min ? fs_out_min : 15000u);  // decimator.h:245
+    const double bw = (double)protect_bw;
+    while (c.rate > floor_rate) {
+        int pick = -1;
+        for (int k = 0; k < PEBBLE_HB_NDESIGNS && pick < 0; k++)
+            if ((double)c.rate >= bw / pebble_hb_designs[k].wpass) pick = k;
+        if (pick < 0) break;
+        c.dec_by2++;
+        c.total *= 2;
+        if (!c.stages.empty() && c.stages.back().ntaps == pebble_hb_designs[pick].ntaps)
+            c.stages.back().stride *= 2;
+        else
+            c.stages.push_back(Stage{pick, pebble_hb_designs[pick].ntaps, 2u});
+        c.rate /= 2;
+    }
+    return c;
+}
+
+const double *halfband_taps(int design) { return pebble_hb_designs[design].h; }
+
+void mixer_amplitudes(float *tab, int n, float *a_inf)
+{
+    double a = 1.0;
+    for (int i = 0; i < n; i++) {
+        tab[i] = (float)a;
+        a = a * (1.95 - a * a);
+    }
+    *a_inf = (float)std::sqrt(0.95);
+}
+
+void fft(std::vector<std::complex<double>> &x, int dir)
+{
+    const size_t n = x.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(x[i], x[j]);
+    }
+    const double sgn = dir >= 0 ? -1.0 : 1.0;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len >> 1;
+        for (size_t k = 0; k < half; k++) {
+            const double ang = sgn * kTwoPi * (double)k / (double)len;
+            const std::complex<double> w(std::cos(ang), std::sin(ang));
+            for (size_t s = k; s < n; s += len) {
+                const std::complex<double> t = x[s + half] * w;
+                x[s + half] = x[s] - t;
+                x[s] += t;
+            }
+        }
+    }
+}
+
+bool fastfir_design(uint32_t fft_size, uint32_t fir_size, double lo, double hi, double offset, double fs,
+                    std::vector<std::complex<double>> &H)
+{
+    lo += offset;
+    hi += offset;
+    if (lo >= hi || lo >= fs / 2.0 || lo <= -fs / 2.0 || hi >= fs / 2.0 || hi <= -fs / 2.0) return false;
+    const double nfl = lo / fs, nfh = hi / fs;
+    const double nfc = (nfh - nfl) / 2.0;            // prototype low-pass cutoff
+    const double nfs = kTwoPi * (nfh + nfl) / 2.0;   // heterodyne to the band centre
+    const double centre = 0.5 * (double)(fir_size - 1);
+    std::vector<std::complex<double>> h(fft_size, std::complex<double>(0, 0));
+    for (uint32_t i = 0; i < fir_size; i++) {
+        // Blackman-Nuttall window, fastfir.cpp:102-111
+        const double w = 0.3635819 - 0.4891775 * std::cos((kTwoPi * i) / (fir_size - 1)) +
+                         0.1365995 * std::cos((2.0 * kTwoPi * i) / (fir_size - 1)) -
+                         0.0106411 * std::cos((3.0 * kTwoPi * i) / (fir_size - 1));
+        const double x = (double)i - centre;
+        const double z = ((double)i == centre) ? 2.0 * nfc : std::sin(kTwoPi * x * nfc) / (kPi * x) * w;
+        h[i] = std::complex<double>(z * std::cos(nfs * x) / (double)fft_size, z * std::sin(nfs * x) / (double)fft_size);
+    }
+    fft(h, +1);
+    H.swap(h);
+    return true;
+}
+
+static double bessel_i0(double x)  // fir.cpp:494-512, series to 1e-9 relative
+{
+    const double x2 = x / 2.0;
+    double sum = 1.0, ds = 1.0, di = 1.0;
+    do {
+        double t = x2 / di;
+        t *= t;
+        ds *= t;
+        sum += ds;
+        di += 1.0;
+    } while (ds >= 1e-9 * sum);
+    return sum;
+}
+
+std::vector<double> fir_lowpass(int force_taps, double scale, double astop, double fpass, double fstop, double fs)
+{
+    const double nfp = fpass / fs, nfs = fstop / fs, nfc = (nfs + nfp) / 2.0;
+    double beta;
+    if (astop < 20.96) beta = 0;
+    else if (astop >= 50.0) beta = .1102 * (astop - 8.71);
+    else beta = .5842 * std::pow(astop - 20.96, 0.4) + .07886 * (astop - 20.96);
+    int ntaps = (int)((astop - 8.0) / (2.285 * kTwoPi * (nfs - nfp)) + 1);
+    if (ntaps > 75) ntaps = 75;
+    if (ntaps < 3) ntaps = 3;
+    if (force_taps) ntaps = force_taps;
+    std::vector<double> h(ntaps);
+    const double centre = .5 * (double)(ntaps - 1), izb = bessel_i0(beta);
+    for (int n = 0; n < ntaps; n++) {
+        double x = (double)n - centre;
+        const double c = ((double)n == centre) ? 2.0 * nfc : std::sin(kTwoPi * x * nfc) / (kPi * x);
+        x = ((double)n - ((double)ntaps - 1.0) / 2.0) / (((double)ntaps - 1.0) / 2.0);
+        h[n] = scale * c * bessel_i0(beta * std::sqrt(1 - x * x)) / izb;
+    }
+    return h;
+}
+
+static Biquad rbj(double f0, double q, double fs, int kind)
+{
+    const double w0 = kTwoPi * f0 / fs, alpha = std::sin(w0) / (2.0 * q), A = 1.0 / (1.0 + alpha);
+    Biquad b;
+    b.a1 = A * (-2.0 * std::cos(w0));
+    b.a2 = A * (1.0 - alpha);
+    if (kind == 0) {  // low-pass, iir.cpp:88-103
+        b.b0 = A * ((1.0 - std::cos(w0)) / 2.0);
+        b.b1 = A * (1.0 - std::cos(w0));
+        b.b2 = b.b0;
+    } else {          // band-reject, iir.cpp:152-167
+        b.b0 = A;
+        b.b1 = A * (-2.0 * std::cos(w0));
+        b.b2 = A;
+    }
+    return b;
+}
+Biquad biquad_lowpass(double f0, double q, double fs) { return rbj(f0, q, fs, 0); }
+Biquad biquad_notch(double f0, double q, double fs) { return rbj(f0, q, fs, 1); }
+
+double blackman_harris(uint32_t n, std::vector<double> &w)
+{
+    // float constants and a float 2*pi, exactly as the reference declares them (windowfunction.cpp:49-51,218-222)
+    const float two_pi = (float)kTwoPi, a0 = 0.35875F, a1 = 0.48829F, a2 = 0.14128F, a3 = 0.01168F;
+    w.resize(n);
+    double sum = 0;
+    const int N = (int)n;
+    for (int i = 0; i < N; i++) {
+        w[i] = a0 - a1 * std::cos(two_pi * (i + 0.5) / N) + a2 * std::cos(2.0 * two_pi * (i + 0.5) / N) -
+               a3 * std::cos(3.0 * two_pi * (i + 0.5) / N);
+        sum += w[i];
+    }
+    return sum / N;
+}
+
+M2 m2_mul(const M2 &x, const M2 &y)
+{
+    return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+M2 m2_pow(M2 x, uint64_t e)
+{
+    M2 r{1, 0, 0, 1};
+    while (e) {
+        if (e & 1) r = m2_mul(r, x);
+        x = m2_mul(x, x);
+        e >>= 1;
+    }
+    return r;
+}
+double spectral_radius(const M2 &x)
+{
+    const double tr = x.a + x.d, det = x.a * x.d - x.b * x.c, disc = tr * tr / 4 - det;
+    if (disc < 0) return std::sqrt(det);
+    const double r = std::sqrt(disc);
+    return std::fmax(std::fabs(tr / 2 + r), std::fabs(tr / 2 - r));
+}
+
+}  // namespace design
+}  // namespace pg

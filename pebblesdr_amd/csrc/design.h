@@ -1,0 +1,59 @@
+// design.h -- host-side (fp64) parameter design for the receive chain: which decimation stages,
+// which taps, which biquads.  Runs once per control change, never per sample; the results are
+// rounded to fp32 and uploaded.  Each routine names the reference code whose numbers it must match.
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <vector>
+
+namespace pg {
+namespace design {
+
+constexpr double kPi = 3.14159265358979323846264338328;     // pebblelib/cpx.h:16
+constexpr double kTwoPi = 6.28318530717958647692528676656;  // pebblelib/cpx.h:18
+
+struct Stage {
+    int design;       // index into the halfband design table (hb_taps.inc)
+    int ntaps;        // 0 => CIC3
+    uint32_t stride;  // decimate-by after merging identical consecutive picks
+};
+struct Chain {
+    std::vector<Stage> stages;
+    uint32_t dec_by2 = 0;   // Decimator::decBy2Stages()
+    uint32_t total = 1;     // D
+    float rate = 0;         // achieved rate (float, as decimator.h:251)
+};
+// Decimator::buildDecimationChain, pebblelib/decimator.cpp:64-149
+Chain build_chain(uint32_t fs_in, uint32_t protect_bw, uint32_t fs_out_min);
+const double *halfband_taps(int design);  // length = ntaps of that design
+
+// Mixer amplitude sequence a_0 = 1, a_{n+1} = a_n (1.95 - a_n^2)  (pebblelib/mixer.cpp:65-67); a_inf = sqrt(.95)
+void mixer_amplitudes(float *tab, int n, float *a_inf);
+
+// in-place radix-2 FFT, fp64; dir +1: e^{-j}, -1: e^{+j}; unscaled (Accelerate semantics, fftaccelerate.cpp:62,95)
+void fft(std::vector<std::complex<double>> &x, int dir);
+
+// CFastFIR::SetupParameters, pebblelib/fastfir.cpp:191-272: frequency-domain H (fft_size), 1/fft_size folded in.
+// returns false on "Filter Parameter error" (H untouched).
+bool fastfir_design(uint32_t fft_size, uint32_t fir_size, double lo, double hi, double offset, double fs,
+                    std::vector<std::complex<double>> &H);
+
+// CFir::InitLPFilter, pebblelib/fir.cpp:246-337 (Kaiser-windowed sinc, clamp 3..75 taps)
+std::vector<double> fir_lowpass(int force_taps, double scale, double astop, double fpass, double fstop, double fs);
+
+// CIir::InitLP / InitBR, pebblelib/iir.cpp:88-103,152-167.  Direct form 2: w = x - a1 w1 - a2 w2; y = b0 w + b1 w1 + b2 w2
+struct Biquad { double b0, b1, b2, a1, a2; };
+Biquad biquad_lowpass(double f0, double q, double fs);
+Biquad biquad_notch(double f0, double q, double fs);
+
+// WindowFunction BLACKMANHARRIS, pebblelib/windowfunction.cpp:214-235; returns coherentGain = sum/N
+double blackman_harris(uint32_t n, std::vector<double> &w);
+
+// 2x2 real matrix helpers for the chunked recurrence scans (state transition powers)
+struct M2 { double a, b, c, d; };
+M2 m2_mul(const M2 &x, const M2 &y);
+M2 m2_pow(M2 x, uint64_t e);
+double spectral_radius(const M2 &x);
+
+}  // namespace design
+}  // namespace pg

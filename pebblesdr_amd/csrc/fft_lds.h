@@ -1,0 +1,146 @@
+// fft_lds.h -- workgroup FFT for N in {2048, 4096, 8192}: 256 work-items, N/256 points per
+// work-item held in registers, Stockham autosort passes (radix 8, with one leading radix-4 or
+// radix-2 pass) exchanged through LDS.  fp32, twiddles from an fp64-rounded table W_N[m] =
+// exp(-2*pi*i*m/N) resident in L1/L2.
+//
+// Register layout ("strided"): x[m] holds element  tid + 256*m.  The first pass reads its butterfly
+// inputs from exactly those slots and the last pass leaves its outputs in exactly those slots, so a
+// forward transform, a pointwise product and an inverse transform chain with no extra exchange
+// (the overlap-save band-pass does that), and global loads/stores of x[] are coalesced.
+//
+// LDS image: element i lives at lpad(i) = i + 4*(i>>5) (float2 units).  The 4-slot pad per 32
+// elements makes the stride-4 / stride-32 scatter of the early passes land on distinct banks
+// for ds_write_b64 (16-lane groups, 32 dword banks) while unit-stride gathers stay conflict-free.
+#pragma once
+#include "common.h"
+
+namespace pg {
+
+__device__ __forceinline__ int lpad(int i) { return i + ((i >> 5) << 2); }
+template <int N> struct FftLds { static constexpr int kSlots = N + (N >> 5) * 4; };
+
+// DIR = +1: forward (e^{-j}), DIR = -1: inverse (e^{+j}); unscaled both ways.
+template <int DIR> __device__ __forceinline__ float2 mul_mj(float2 a)  // a * (-j*DIR)
+{
+    return DIR > 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+template <int DIR> __device__ __forceinline__ float2 twid(float2 w)  // table holds forward twiddles
+{
+    return DIR > 0 ? w : make_float2(w.x, -w.y);
+}
+
+template <int DIR> __device__ __forceinline__ void bfly2(float2 *u)
+{
+    float2 a = u[0], b = u[1];
+    u[0] = cadd(a, b);
+    u[1] = csub(a, b);
+}
+template <int DIR> __device__ __forceinline__ void bfly4(float2 *u)
+{
+    float2 t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]);
+    float2 t2 = cadd(u[1], u[3]), t3 = mul_mj<DIR>(csub(u[1], u[3]));
+    u[0] = cadd(t0, t2);
+    u[2] = csub(t0, t2);
+    u[1] = cadd(t1, t3);
+    u[3] = csub(t1, t3);
+}
+template <int DIR> __device__ __forceinline__ void bfly8(float2 *u)
+{
+    float2 e[4] = {u[0], u[2], u[4], u[6]};
+    float2 o[4] = {u[1], u[3], u[5], u[7]};
+    bfly4<DIR>(e);
+    bfly4<DIR>(o);
+    const float c = 0.70710678118654752440f;
+    // W8^1 = c(1 - j*DIR), W8^2 = -j*DIR, W8^3 = c(-1 - j*DIR)
+    float2 o1 = DIR > 0 ? make_float2(c * (o[1].x + o[1].y), c * (o[1].y - o[1].x))
+                         : make_float2(c * (o[1].x - o[1].y), c * (o[1].y + o[1].x));
+    float2 o2 = mul_mj<DIR>(o[2]);
+    float2 o3 = DIR > 0 ? make_float2(c * (o[3].y - o[3].x), -c * (o[3].x + o[3].y))
+                         : make_float2(-c * (o[3].x + o[3].y), c * (o[3].x - o[3].y));
+    u[0] = cadd(e[0], o[0]); u[4] = csub(e[0], o[0]);
+    u[1] = cadd(e[1], o1);   u[5] = csub(e[1], o1);
+    u[2] = cadd(e[2], o2);   u[6] = csub(e[2], o2);
+    u[3] = cadd(e[3], o3);   u[7] = csub(e[3], o3);
+}
+template <int R, int DIR> __device__ __forceinline__ void bfly(float2 *u)
+{
+    if (R == 2) bfly2<DIR>(u);
+    else if (R == 4) bfly4<DIR>(u);
+    else bfly8<DIR>(u);
+}
+
+// One Stockham pass.  P = product of the radices of the passes before this one.
+template <int N, int R, int P, int DIR, bool FIRST, bool LAST>
+__device__ __forceinline__ void fft_pass(float2 (&x)[N / 256], float2 *lds, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int E = N / 256, Q = E / R;
+    static_assert(E % R == 0 && Q >= 1, "points per work-item must be a multiple of the radix");
+    if (!FIRST) {
+#pragma unroll
+        for (int m = 0; m < E; m++) x[m] = lds[lpad(tid + 256 * m)];
+        __syncthreads();  // all gathers done before any work-item scatters again
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int b = tid + 256 * q;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) u[r] = x[q + r * Q];
+        const int k = b & (P - 1);
+        if (P > 1) {
+            const int i1 = k * (N / (P * R));
+            const float2 w1 = twid<DIR>(tw[i1]);
+            u[1] = cmul(u[1], w1);
+            if (R >= 4) {
+                const float2 w2 = twid<DIR>(tw[2 * i1]);
+                const float2 w3 = cmul(w1, w2);
+                u[2] = cmul(u[2], w2);
+                u[3] = cmul(u[3], w3);
+                if (R == 8) {
+                    const float2 w4 = twid<DIR>(tw[4 * i1]);
+                    u[4] = cmul(u[4], w4);
+                    u[5] = cmul(u[5], cmul(w4, w1));
+                    u[6] = cmul(u[6], cmul(w4, w2));
+                    u[7] = cmul(u[7], cmul(w4, w3));
+                }
+            }
+        }
+        bfly<R, DIR>(u);
+        if (LAST) {
+            // P == N/R here, so k == b and output r lands on element b + r*N/R = tid + 256*(q + r*Q)
+#pragma unroll
+            for (int r = 0; r < R; r++) x[q + r * Q] = u[r];
+        } else {
+            const int j = (b - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; r++) lds[lpad(j + r * P)] = u[r];
+        }
+    }
+    if (!LAST) __syncthreads();
+}
+
+// Whole transform, strided registers in and out.  lds: FftLds<N>::kSlots float2.  All 256 work-items call.
+template <int N, int DIR>
+__device__ __forceinline__ void fft_regs(float2 (&x)[N / 256], float2 *lds, const float2 *__restrict__ tw, int tid)
+{
+    static_assert(N == 2048 || N == 4096 || N == 8192, "supported workgroup FFT sizes");
+    if (N == 2048) {
+        fft_pass<N, 4, 1, DIR, true, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 4, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 32, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 256, DIR, false, true>(x, lds, tw, tid);
+    } else if (N == 4096) {
+        fft_pass<N, 8, 1, DIR, true, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 8, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 64, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 512, DIR, false, true>(x, lds, tw, tid);
+    } else {
+        fft_pass<N, 2, 1, DIR, true, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 2, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 16, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 128, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, 8, 1024, DIR, false, true>(x, lds, tw, tid);
+    }
+}
+
+}  // namespace pg

@@ -1,0 +1,164 @@
+// kernels_demod.h -- demod-rate kernels: linear recurrences as wave-parallel scans, FM discriminator.
+//
+// The reference's demodulators are serial per sample: AM DC-block (demod_am.cpp:52-57), CIir
+// biquads (pebblelib/iir.cpp:176-207) and the one-pole de-emphasis (demod_wfm.cpp:476-485).  All are
+// LINEAR recurrences, so a wave evaluates 2048 samples at once: lane l owns 32 consecutive samples,
+// runs them from a zero state, the 64 end states are combined with a Hillis-Steele scan using the
+// precomputed transition powers M^(32*2^k), and each lane re-runs its samples from its true entry state.
+// Recurrence arithmetic is fp64 (the DC-block pole 0.9999 needs it); samples are stored fp32.
+//
+// Across workgroups a long single-channel stream is cut into chunks; a chunk that does not start at
+// the call boundary warms up on `warm_sub` preceding sub-chunks from a zero state (host picks warm_sub
+// so the pole radius^samples < 1e-13, else it selects the exact sequential mode, warm_sub < 0).
+#pragma once
+#include "params.h"
+
+namespace pg {
+
+
+__device__ __forceinline__ int spad(int i) { return i + (i >> 5); }  // lane stride 32 -> 33: conflict-free
+
+__device__ __forceinline__ double sec_step(const ScanSection &S, double &s0, double &s1, double u)
+{
+    double y;
+    if (S.type == kOnePoleDiff) {        // m_amDc = ALPHA*m_amDcLast + mag; out = m_amDc - m_amDcLast
+        const double dn = (S.c[0] * s0) + u;
+        y = dn - s0;
+        s0 = dn;
+    } else if (S.type == kOnePoleAvg) {  // ave = (1-a)*ave + a*in; out = 2*ave
+        s0 = (1.0 - S.c[0]) * s0 + S.c[0] * u;
+        y = s0 * 2.0;
+    } else {                              // w0 = in - A1*w1 - A2*w2; out = B0*w0 + B1*w1 + B2*w2
+        const double w0 = u - S.c[3] * s0 - S.c[4] * s1;
+        y = S.c[0] * w0 + S.c[1] * s0 + S.c[2] * s1;
+        s1 = s0;
+        s0 = w0;
+    }
+    return y;
+}
+
+// One section over one sub-chunk held in LDS (padded float array), in place.  c0/c1: state entering
+// the sub-chunk, replaced by the state after its last valid sample.  Must be called by all 64 lanes.
+__device__ __forceinline__ void scan_sub(const ScanSection &S, float *buf, int nv, double &c0, double &c1, int lane)
+{
+    const int base = lane * kSeg;
+    int cnt = nv - base;
+    cnt = cnt < 0 ? 0 : (cnt > kSeg ? kSeg : cnt);
+    double s0 = lane == 0 ? c0 : 0.0, s1 = lane == 0 ? c1 : 0.0;
+    for (int i = 0; i < kSeg; i++) {
+        const double u = i < cnt ? (double)buf[spad(base + i)] : 0.0;
+        (void)sec_step(S, s0, s1, u);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double t0 = __shfl_up(s0, 1u << k), t1 = __shfl_up(s1, 1u << k);
+        if (lane >= (1 << k)) {
+            s0 += S.P[k][0] * t0 + S.P[k][1] * t1;
+            s1 += S.P[k][2] * t0 + S.P[k][3] * t1;
+        }
+    }
+    double e0 = __shfl_up(s0, 1u), e1 = __shfl_up(s1, 1u);
+    if (lane == 0) { e0 = c0; e1 = c1; }
+    for (int i = 0; i < cnt; i++) {
+        const int a = spad(base + i);
+        buf[a] = (float)sec_step(S, e0, e1, (double)buf[a]);
+    }
+    const int lf = (nv - 1) >> 5;
+    c0 = __shfl(e0, lf);
+    c1 = __shfl(e1, lf);
+}
+
+// MODE 0: complex in -> complex out, both components filtered independently (CIir complex, iir.cpp:191-207)
+// MODE 1: real: in.x -> (y, y)
+// MODE 2: magnitude: |in| -> (y, y)      (Demod_AM::processBlockFiltered front half)
+// state layout: [channel][section][component(2)][2] doubles.  grid (n_blocks, n_listed_channels), block 64.
+template <int MODE, int NSEC>
+static __global__ __launch_bounds__(64) void k_iir_scan(const float2 *__restrict__ in, long long in_pitch,
+                                                  float2 *__restrict__ out, long long out_pitch, long long n,
+                                                  ScanParams<NSEC> sp, const double *__restrict__ state_in,
+                                                  double *__restrict__ state_out, int sub_per_block, int warm_sub,
+                                                  const int *__restrict__ chan_list)
+{
+    __shared__ float re[kSub + kSub / 32 + 1];
+    __shared__ float im[kSub + kSub / 32 + 1];
+    const int lane = threadIdx.x;
+    const int c = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    const long long nsub = (n + kSub - 1) / kSub;
+    const long long first_out = (long long)blockIdx.x * sub_per_block;
+    long long last = first_out + sub_per_block;
+    if (last > nsub) last = nsub;
+    long long start = warm_sub < 0 ? 0 : first_out - warm_sub;
+    if (start < 0) start = 0;
+
+    double st[NSEC][2][2];
+#pragma unroll
+    for (int s = 0; s < NSEC; s++)
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            const double *p = state_in + (((long long)c * NSEC + s) * 2 + comp) * 2;
+            st[s][comp][0] = start == 0 ? p[0] : 0.0;
+            st[s][comp][1] = start == 0 ? p[1] : 0.0;
+        }
+
+    const float2 *x = in + (long long)c * in_pitch;
+    float2 *y = out + (long long)c * out_pitch;
+    for (long long sub = start; sub < last; sub++) {
+        const long long off = sub * kSub;
+        int nv = (int)((n - off) < kSub ? (n - off) : kSub);
+        for (int j = lane; j < nv; j += 64) {
+            const float2 v = x[off + j];
+            if (MODE == 0) { re[spad(j)] = v.x; im[spad(j)] = v.y; }
+            else if (MODE == 1) re[spad(j)] = v.x;
+            else re[spad(j)] = sqrtf(v.x * v.x + v.y * v.y);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSEC; s++) {
+            scan_sub(sp.sec[s], re, nv, st[s][0][0], st[s][0][1], lane);
+            if (MODE == 0) scan_sub(sp.sec[s], im, nv, st[s][1][0], st[s][1][1], lane);
+        }
+        __syncthreads();
+        if (sub >= first_out) {
+            for (int j = lane; j < nv; j += 64) {
+                const float a = re[spad(j)];
+                y[off + j] = make_float2(a, MODE == 0 ? im[spad(j)] : a);
+            }
+        }
+        __syncthreads();
+    }
+    if (last == nsub && lane == 0) {
+#pragma unroll
+        for (int s = 0; s < NSEC; s++)
+#pragma unroll
+            for (int comp = 0; comp < 2; comp++) {
+                double *p = state_out + (((long long)c * NSEC + s) * 2 + comp) * 2;
+                p[0] = st[s][comp][0];
+                p[1] = st[s][comp][1];
+            }
+    }
+}
+
+// FM discriminator, demod_wfm.cpp:214-220: out = gain * atan2(I1*Q0 - I0*Q1, I1*I0 + Q1*Q0), written to
+// both components.  in[-1] is the previous call's last sample (head-room 1).  grid (ceil(n/256), C).
+static __global__ __launch_bounds__(256) void k_discrim(const float2 *__restrict__ in, long long in_pitch,
+                                                  float2 *__restrict__ out, long long out_pitch, long long n, float gain)
+{
+    const int c = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 *x = in + (long long)c * in_pitch;
+    const float2 d1 = x[i - 1], d0 = x[i];
+    const float v = gain * atan2f(d1.x * d0.y - d0.x * d1.y, d1.x * d0.x + d1.y * d0.y);
+    out[(long long)c * out_pitch + i] = make_float2(v, v);
+}
+
+// copy (the WFM IIR low-pass is skipped below 150 kHz, demod_wfm.cpp:210-212).  grid (ceil(n/256), C)
+static __global__ __launch_bounds__(256) void k_copy(const float2 *__restrict__ in, long long in_pitch,
+                                               float2 *__restrict__ out, long long out_pitch, long long n)
+{
+    const int c = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[(long long)c * out_pitch + i] = in[(long long)c * in_pitch + i];
+}
+
+}  // namespace pg

@@ -1,0 +1,46 @@
+// kernels_fastfir.h -- CFastFIR::ProcessData (pebblelib/fastfir.cpp:281-334) as batched overlap-save.
+//
+// One workgroup per (block, channel): gather N = L + (taps-1) samples [overlap | L new] straight into
+// the strided register layout, forward FFT, multiply by the channel's H (1/N already folded into the
+// taps, fastfir.cpp:244-245), inverse FFT, keep samples taps-1 .. N-1.  Forward-last and inverse-first
+// passes share the register layout (fft_lds.h), so the product needs no exchange.
+//
+// The input buffer carries taps-1 samples of head-room holding the previous call's tail, which is
+// exactly m_pFFTOverlapBuf (zero before the first call, fastfir.cpp:104-105).
+//
+// Bound: HBM.  Algorithmic bytes per demod-rate sample: 8 read + 8 written (+ H once per block: with
+// taps-1 = N/2 the overlap doubles the read to 16 B unless L2 serves the second touch).
+#pragma once
+#include "fft_lds.h"
+
+namespace pg {
+
+template <int N>
+__global__ __launch_bounds__(256) void k_fastfir(const float2 *__restrict__ in, long long in_pitch,
+                                                  float2 *__restrict__ out, long long out_pitch,
+                                                  const float2 *__restrict__ H, const float2 *__restrict__ tw,
+                                                  int overlap /* taps-1 */)
+{
+    constexpr int E = N / 256;
+    __shared__ float2 lds[FftLds<N>::kSlots];
+    const int tid = threadIdx.x, c = blockIdx.y;
+    const int L = N - overlap;
+    const long long b = blockIdx.x;
+    const float2 *x = in + (long long)c * in_pitch + b * L - overlap;  // first sample of [overlap | new]
+    const float2 *h = H + (long long)c * N;
+    float2 v[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) v[m] = x[tid + 256 * m];
+    fft_regs<N, +1>(v, lds, tw, tid);
+#pragma unroll
+    for (int m = 0; m < E; m++) v[m] = cmul(h[tid + 256 * m], v[m]);  // CpxMpy, fastfir.cpp:325-334
+    fft_regs<N, -1>(v, lds, tw, tid);
+    float2 *y = out + (long long)c * out_pitch + b * L;
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int i = tid + 256 * m;
+        if (i >= overlap) y[i - overlap] = v[m];
+    }
+}
+
+}  // namespace pg

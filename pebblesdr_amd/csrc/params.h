@@ -1,0 +1,47 @@
+// params.h -- plain structs shared by the host objects and the kernels (passed by value or uploaded).
+#pragma once
+#include "common.h"
+
+namespace pg {
+
+// Per-channel oscillator block, rewritten by the host before every call (a few hundred bytes/channel).
+// Mixer::processBlock (pebblelib/mixer.cpp:48-81) restated in closed form:
+//   osc_i = a_{n0+i} * exp(j*2*pi*(phase0 + (i+1)*inc)),  a_0 = 1, a_{k+1} = a_k*(1.95 - a_k^2)
+struct ChanOsc {
+    double phase0;          // cycles; accumulated phase at the end of the previous call (0 after a retune)
+    double inc;             // cycles per sample = -f/Fs (the reference negates f, mixer.cpp:31)
+    uint32_t n0;            // samples since the last retune, saturated at kAmpTab
+    uint32_t mix_on;        // 0 => f == 0: Mixer returns its input untouched (mixer.cpp:51-53)
+    float2 step[kMaxTaps];  // exp(j*2*pi*d*inc), d = 0..kMaxTaps-1, rounded from fp64
+};
+
+struct FirTaps {
+    int ntaps;
+    int stride;
+    int cic3;   // 1: CIC3 decimate-by-`stride` in the reference's merged form (decimator.cpp:719-737)
+    float gain; // applied to the output (gain restore on the last stage, receiver.cpp:935-938), else 1
+    float h[kMaxTaps];
+};
+
+constexpr int kSub = 2048;   // samples one wave scans at a time (64 lanes x 32)
+constexpr int kSeg = 32;
+
+enum ScanType { kOnePoleDiff = 0, kOnePoleAvg = 1, kBiquadDf2 = 2 };
+
+struct ScanSection {
+    int type;
+    int pad_;
+    double c[5];      // kOnePoleDiff: c0 = alpha.  kOnePoleAvg: c0 = alpha.  kBiquadDf2: b0 b1 b2 a1 a2
+    double P[6][4];   // M^(kSeg * 2^k), row-major 2x2, k = 0..5
+};
+template <int NSEC> struct ScanParams { ScanSection sec[NSEC]; };
+
+struct SpectrumParams {
+    long long in_pitch;      // samples between streams
+    long long n_frames;      // frames in this call (per stream)
+    int frames_per_group;    // G
+    float scale;             // 1 / (coherentGain * maxBinPower), maxBinPower = NF (fft.cpp:84)
+    long long out_pitch;     // floats between streams (= n_frames*bins)
+};
+
+}  // namespace pg

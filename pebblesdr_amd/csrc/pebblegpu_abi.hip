@@ -1,0 +1,169 @@
+// pebblegpu_abi.hip -- extern "C" surface declared in include/pebblegpu.h (receiver bank + memory plumbing).
+#include <cmath>
+#include <new>
+#include "receiver.h"
+
+struct pebblegpu_receiver {
+    pg::Receiver rx;
+};
+
+using pg::fail;
+
+extern "C" {
+
+const char *pebblegpu_last_error(void) { return pg::last_error().c_str(); }
+int pebblegpu_abi_version(void) { return PEBBLEGPU_ABI_VERSION; }
+
+int pebblegpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int need_device(int device)
+{
+    int n = pebblegpu_device_count();
+    if (n <= 0) return fail(PEBBLEGPU_E_NO_DEVICE, "no HIP device visible: libpebblegpu has no CPU path");
+    if (device < 0 || device >= n) return fail(PEBBLEGPU_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    PG_HIP(hipSetDevice(device));
+    return 0;
+}
+
+int pebblegpu_malloc(int device, size_t bytes, void **dptr)
+{
+    if (!dptr) return fail(PEBBLEGPU_E_INVALID, "null dptr");
+    if (int rc = need_device(device)) return rc;
+    PG_HIP(hipMalloc(dptr, bytes));
+    return 0;
+}
+int pebblegpu_free(int device, void *dptr)
+{
+    if (int rc = need_device(device)) return rc;
+    PG_HIP(hipFree(dptr));
+    return 0;
+}
+int pebblegpu_memcpy_h2d(int device, void *dst, const void *src, size_t bytes)
+{
+    if (int rc = need_device(device)) return rc;
+    PG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int pebblegpu_memcpy_d2h(int device, void *dst, const void *src, size_t bytes)
+{
+    if (int rc = need_device(device)) return rc;
+    PG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int pebblegpu_memset(int device, void *dst, int value, size_t bytes)
+{
+    if (int rc = need_device(device)) return rc;
+    PG_HIP(hipMemset(dst, value, bytes));
+    return 0;
+}
+int pebblegpu_device_synchronize(int device)
+{
+    if (int rc = need_device(device)) return rc;
+    PG_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out)
+{
+    if (!cfg || !out) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    if (cfg->struct_size != sizeof(pebblegpu_config)) return fail(PEBBLEGPU_E_INVALID, "pebblegpu_config size mismatch (ABI %d)", PEBBLEGPU_ABI_VERSION);
+    if (int rc = need_device(cfg->device)) return rc;
+    pebblegpu_receiver *h = new (std::nothrow) pebblegpu_receiver();
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    int rc = h->rx.create(cfg);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int pebblegpu_receiver_destroy(pebblegpu_receiver *rx)
+{
+    delete rx;
+    return 0;
+}
+
+int pebblegpu_receiver_info(const pebblegpu_receiver *h, pebblegpu_info *info)
+{
+    if (!h || !info) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    const pg::Receiver &r = h->rx;
+    memset(info, 0, sizeof(*info));
+    info->demod_rate = (double)r.chain.rate;
+    info->demod_rate_int = r.demod_rate_int;
+    info->dec_by2_stages = r.chain.dec_by2;
+    info->total_decimation = r.chain.total;
+    info->chain_len = (uint32_t)r.chain.stages.size();
+    for (size_t i = 0; i < r.chain.stages.size() && i < 16; i++) {
+        info->stage_taps[i] = (uint32_t)r.chain.stages[i].ntaps;
+        info->stage_stride[i] = r.chain.stages[i].stride;
+    }
+    info->superframe = r.superframe;
+    info->n_streams = r.S;
+    info->spectrum_bins = r.bins;
+    return 0;
+}
+
+int pebblegpu_set_mixer_freq(pebblegpu_receiver *h, uint32_t channel, double freq_hz)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_mixer(channel, freq_hz);
+}
+int pebblegpu_set_bandpass(pebblegpu_receiver *h, uint32_t channel, double lo_hz, double hi_hz)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_bandpass(channel, lo_hz, hi_hz);
+}
+int pebblegpu_set_demod_mode(pebblegpu_receiver *h, uint32_t channel, int mode)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_mode(channel, mode);
+}
+
+int pebblegpu_receiver_process(pebblegpu_receiver *h, const void *d_iq, uint64_t n_samples)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.process((const float2 *)d_iq, n_samples, h->rx.bins != 0, true);
+}
+const void *pebblegpu_receiver_audio(const pebblegpu_receiver *h, uint64_t *samples_per_channel, uint64_t *pitch_samples)
+{
+    if (!h) return nullptr;
+    if (samples_per_channel) *samples_per_channel = h->rx.last_audio_n;
+    if (pitch_samples) *pitch_samples = (uint64_t)h->rx.audio.pitch;
+    return h->rx.audio.data(0);
+}
+const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *h, uint64_t *frames_per_stream)
+{
+    if (!h) return nullptr;
+    if (frames_per_stream) *frames_per_stream = h->rx.last_spec_frames;
+    return h->rx.d_spec;
+}
+int pebblegpu_receiver_synchronize(pebblegpu_receiver *h)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.sync();
+}
+int pebblegpu_receiver_last_ms(const pebblegpu_receiver *h, int which, float *ms)
+{
+    if (!h || !ms || which < 0 || which > 5) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    const pg::Timers &t = h->rx.tm;
+    // 0 whole call; 1 spectrum; 2 mixer+first stage; 3 later stages; 4 FastFIR; 5 demod
+    static const int a[6] = {0, 0, 1, 2, 3, 4}, b[6] = {6, 1, 2, 3, 4, 5};
+    PG_HIP(hipEventSynchronize(t.ev[6]));
+    PG_HIP(hipEventElapsedTime(ms, t.ev[a[which]], t.ev[b[which]]));
+    return 0;
+}
+int pebblegpu_process_iq(pebblegpu_receiver *h, const double *iq, uint16_t n, double *audio, uint32_t *n_audio,
+                         double *spectrum_db)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.process_iq(iq, n, audio, n_audio, spectrum_db);
+}
+
+}  // extern "C"

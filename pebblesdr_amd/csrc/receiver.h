@@ -1,0 +1,185 @@
+// receiver.h -- host-side objects behind the C ABI (include/pebblegpu.h).
+//
+// Five device "cores", one per reference class on the hot path, each owning its device state and
+// launching its kernels on a caller-supplied stream:
+//   DecimCore   <- Mixer + Decimator           (pebblelib/mixer.cpp, decimator.cpp)
+//   FastFirCore <- CFastFIR / BandPassFilter   (pebblelib/fastfir.cpp, application/bandpassfilter.cpp)
+//   AmCore      <- Demod_AM                    (application/demod/demod_am.cpp)
+//   WfmCore     <- Demod_WFM (mono)            (application/demod/demod_wfm.cpp)
+//   SpectrumCore<- FFT::fftSpectrum            (pebblelib/fft.cpp)
+// Receiver composes them the way Receiver::processIQData does; the stand-alone steps (steps.hip) wrap one
+// core each behind the reference's per-class call shapes.
+#pragma once
+#include <complex>
+#include <mutex>
+#include <vector>
+#include "../../include/pebblegpu.h"
+#include "common.h"
+#include "design.h"
+#include "params.h"
+
+namespace pg {
+
+// [channel][hist | data] complex buffer; data(c) points at the first new sample, data(c)[-hist..-1] is history.
+struct HistBuf {
+    float2 *base = nullptr;
+    long long pitch = 0;  // samples per channel row (hist + capacity, even)
+    int hist = 0;
+    long long cap = 0;
+    int chans = 0;
+    float2 *data(int c = 0) const { return base + (long long)c * pitch + hist; }
+    int alloc(int channels, int hist_len, long long capacity);
+    void release();
+};
+
+void fill_scan_section(ScanSection &s, int type, const double *c);
+int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
+int make_twiddles(int n, float2 **d_tw);
+
+// ---- oscillator bank (Mixer state for C channels) ----
+struct OscBank {
+    struct Ctl { double freq = 0, inc = 0, phase0 = 0; uint64_t n0 = 0; bool dirty = true; };
+    double fs = 0;
+    uint32_t C = 0;
+    std::vector<Ctl> ctl;
+    std::vector<ChanOsc> h_osc;
+    ChanOsc *d_osc = nullptr;
+    float *d_amp = nullptr;
+    float a_inf = 0;
+    int init(uint32_t channels, double sample_rate);
+    void release();
+    void retune(uint32_t ch, double f);           // Mixer::setFrequency, mixer.cpp:25-40
+    int upload(hipStream_t s);                     // refresh the device blocks (sync: host staging is pageable)
+    void advance(uint64_t n);                      // after a call consumed n samples
+};
+
+// ---- Mixer + Decimator ----
+struct DecimCore {
+    design::Chain chain;
+    uint32_t C = 0;
+    std::vector<HistBuf> stage;      // output of merged stage s
+    std::vector<FirTaps> taps;
+    std::vector<long long> lens;     // lengths produced by the last run
+    float *d_taps = nullptr;         // [stages][kMaxTaps]
+    float2 *d_hist_mixed = nullptr;  // [C][kMaxTaps]: mixed-sample history of stage 0
+    // last_hist: head-room of the final buffer (what the consumer looks back at); last_gain: folded into the final stage
+    int init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain);
+    void release();
+    // runs all stages; n must be a multiple of chain.total and every stage must see >= its consumer's history
+    int run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
+            hipEvent_t after_first = nullptr);
+    int save_tails(hipStream_t s);
+    const HistBuf &out() const { return stage.back(); }
+    long long out_len() const { return lens.back(); }
+};
+
+// ---- CFastFIR ----
+struct FastFirCore {
+    uint32_t C = 0, fft_n = 2048, taps = 1025;
+    float2 *d_H = nullptr, *d_tw = nullptr;
+    int init(uint32_t channels, uint32_t fft_size, uint32_t fir_size);
+    void release();
+    long long block_len() const { return (long long)fft_n - (taps - 1); }
+    // *ok = false (and H left alone) on the reference's "Filter Parameter error"
+    int design(hipStream_t s, uint32_t ch, double lo, double hi, double offset, double rate, bool *ok);
+    // in: buffer with taps-1 head-room; n multiple of block_len()
+    int run(hipStream_t s, const HistBuf &in, long long n, float2 *out, long long out_pitch);
+};
+
+// ---- Demod_AM ----
+struct AmCore {
+    uint32_t C = 0;
+    double rate = 0;
+    HistBuf tmp;                    // DC-blocked magnitude, head-room for the audio FIR
+    float *d_taps = nullptr;        // [C][kMaxTaps]
+    int *d_ntaps = nullptr, *d_list = nullptr;
+    double *d_state = nullptr;      // [C][1][2][2]
+    ScanParams<1> scan;
+    std::vector<int> list;
+    int init(uint32_t channels, double demod_rate, long long max_n);
+    void release();
+    int set_bandwidth(hipStream_t s, uint32_t ch, double bw);   // Demod_AM::setBandwidth, demod_am.cpp:17-21
+    int set_list(hipStream_t s, const std::vector<int> &am_channels);
+    // in/out rows may be the same buffer (the scan reads `in`, the FIR writes `out`)
+    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+};
+
+// ---- Demod_WFM mono ----
+struct WfmCore {
+    uint32_t C = 0;
+    double rate = 0;
+    HistBuf a, b, c;                // low-passed IQ (hist 1), discriminator (hist FIR), FIR out
+    float *d_taps = nullptr;
+    int ntaps = 0;
+    bool lp_on = false;
+    ScanParams<1> lp;
+    ScanParams<2> dn;
+    int warm_lp = -1, warm_dn = -1, parity = 0;
+    double *d_lp_state[2] = {nullptr, nullptr}, *d_dn_state[2] = {nullptr, nullptr};
+    int init(uint32_t channels, double demod_rate, long long max_n);
+    void release();
+    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+};
+
+// ---- FFT::fftSpectrum ----
+struct SpectrumCore {
+    uint32_t S = 0, nf = 2048, bins = 0;
+    float *d_window = nullptr, *d_prev[2] = {nullptr, nullptr};
+    float2 *d_tw_nf = nullptr, *d_tw_bins = nullptr;
+    float scale = 0;
+    int parity = 0;
+    int init(uint32_t streams, uint32_t frame, uint32_t fft_size);
+    void release();
+    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out);
+};
+
+struct Timers {
+    hipEvent_t ev[8] = {};
+};
+
+class Receiver {
+public:
+    int create(const pebblegpu_config *cfg);
+    ~Receiver();
+    int set_mixer(uint32_t ch, double f);
+    int set_bandpass(uint32_t ch, double lo, double hi);
+    int set_mode(uint32_t ch, int mode);
+    int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
+    int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
+    int sync();
+
+    int device = 0;
+    double fs = 0;
+    uint32_t nf = 2048, C = 1, S = 1, bins = 0, ff_n = 2048, ff_taps = 1025, max_sf = 1;
+    bool shared_input = false, wfm = false;
+    design::Chain chain;
+    uint32_t demod_rate_int = 0;
+    uint64_t superframe = 0;
+    uint64_t last_audio_n = 0, last_spec_frames = 0;
+    Timers tm;
+    HistBuf audio;   // [C][k*nf]
+    float *d_spec = nullptr;
+
+private:
+    struct ChanCtl {
+        int mode = 0;
+        double lo = 0, hi = 0, am_bw = 16000;  // Demod_AM ctor default (demod_am.cpp:9)
+        bool bp_valid = false, bp_dirty = false, am_dirty = true;
+    };
+    int apply_controls();
+    std::mutex mu_;
+    hipStream_t stream_ = nullptr;
+    std::vector<ChanCtl> ctl_;
+    bool am_list_dirty_ = true;
+    OscBank osc_;
+    DecimCore dec_;
+    FastFirCore ff_;
+    AmCore am_;
+    WfmCore wfmc_;
+    SpectrumCore spec_;
+    float2 *d_stage_in_ = nullptr;
+    std::vector<float> h_frame_, h_out_;
+    uint64_t acc_frames_ = 0;
+};
+
+}  // namespace pg

@@ -1,0 +1,233 @@
+// receiver.hip -- the receiver bank: Receiver::processIQData's DSP (application/receiver.cpp:826-987)
+// for C tuned channels, composed from the device cores in the reference's step order.
+#include <cmath>
+#include "receiver.h"
+
+namespace pg {
+
+static long long lcm_ll(long long a, long long b)
+{
+    long long x = a, y = b;
+    while (y) { long long t = x % y; x = y; y = t; }
+    return a / x * b;
+}
+
+int Receiver::create(const pebblegpu_config *cfg)
+{
+    device = cfg->device;
+    fs = cfg->sample_rate;
+    nf = cfg->frames_per_buffer ? cfg->frames_per_buffer : 2048;  // settings.cpp:57
+    C = cfg->n_channels;
+    shared_input = cfg->shared_input != 0;
+    S = shared_input ? 1 : C;
+    wfm = cfg->wfm != 0;
+    bins = cfg->spectrum_bins;
+    ff_n = cfg->fastfir_fft ? cfg->fastfir_fft : 2048;      // fastfir.cpp:65
+    ff_taps = cfg->fastfir_taps ? cfg->fastfir_taps : 1025;  // fastfir.cpp:66
+    max_sf = cfg->max_superframes ? cfg->max_superframes : 1;
+    if (C == 0 || fs <= 0 || fs > 4.0e9 || fs != std::floor(fs)) return fail(PEBBLEGPU_E_INVALID, "bad channel count or sample rate");
+    if (nf < 256 || nf > 65535) return fail(PEBBLEGPU_E_INVALID, "frames_per_buffer must be 256..65535 (quint16, device_interfaces.h:32)");
+    PG_HIP(hipSetDevice(device));
+    PG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    for (auto &e : tm.ev) PG_HIP(hipEventCreate(&e));
+
+    chain = design::build_chain((uint32_t)fs, wfm ? 200000u : 30000u, 0);  // receiver.cpp:195,213
+    if (chain.stages.empty() || chain.stages.size() > (size_t)kMaxStages)
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "sample rate %.0f yields no decimation chain; not built", fs);
+    demod_rate_int = (uint32_t)(int)chain.rate;  // int members, receiver.h:165-166
+    if (!wfm && (ff_taps < 2 || ff_taps > ff_n)) return fail(PEBBLEGPU_E_INVALID, "FastFIR taps must be in [2, fft size]");
+    const long long L = wfm ? (long long)nf : (long long)ff_n - ((long long)ff_taps - 1);
+    superframe = (uint64_t)chain.total * (uint64_t)lcm_ll(nf, L);
+    const long long max_n = (long long)max_sf * (long long)superframe;
+    const long long nd_max = max_n / chain.total;
+
+    ctl_.assign(C, ChanCtl());
+    for (auto &c : ctl_) c.mode = wfm ? PEBBLEGPU_DM_FMM : PEBBLEGPU_DM_AM;  // Demod ctor default dmAM, demod.cpp:56
+    if (int rc = osc_.init(C, fs)) return rc;
+    // "Restore gain lost in decimation" 10^(2*stages/20) only on the narrow branch (receiver.cpp:935-938 vs :854-901)
+    const float gain = wfm ? 1.f : (float)std::pow(10.0, (double)(chain.dec_by2 * 2) / 20.0);
+    if (int rc = dec_.init(C, chain, max_n, wfm ? 0 : (int)ff_taps - 1, gain)) return rc;
+    if (int rc = audio.alloc((int)C, 0, nd_max)) return rc;
+    if (!wfm) {
+        if (int rc = ff_.init(C, ff_n, ff_taps)) return rc;
+        if (int rc = am_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_AM(m_inputSampleRate), demod.cpp:62
+    } else {
+        if (int rc = wfmc_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_WFM(m_inputWfmSampleRate), demod.cpp:65
+    }
+    if (bins) {
+        if (int rc = spec_.init(S, nf, bins)) return rc;
+        bins = spec_.bins;
+        PG_HIP(hipMalloc((void **)&d_spec, sizeof(float) * (size_t)(max_n / nf) * bins * S));
+    }
+    return 0;
+}
+
+Receiver::~Receiver()
+{
+    (void)hipSetDevice(device);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    osc_.release(); dec_.release(); ff_.release(); am_.release(); wfmc_.release(); spec_.release();
+    audio.release();
+    if (d_spec) (void)hipFree(d_spec);
+    if (d_stage_in_) (void)hipFree(d_stage_in_);
+    for (auto &e : tm.ev) if (e) (void)hipEventDestroy(e);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Receiver::set_mixer(uint32_t ch, double f)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    std::lock_guard<std::mutex> g(mu_);
+    osc_.retune(ch, f);
+    return 0;
+}
+
+int Receiver::set_mode(uint32_t ch, int mode)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (wfm) {
+        if (mode != PEBBLEGPU_DM_FMM) return fail(PEBBLEGPU_E_UNSUPPORTED, "a WFM bank demodulates FMM (mono) only");
+    } else if (mode == PEBBLEGPU_DM_SAM || mode == PEBBLEGPU_DM_FMN || mode == PEBBLEGPU_DM_FMM || mode == PEBBLEGPU_DM_FMS ||
+               mode < 0 || mode > PEBBLEGPU_DM_NONE) {
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d is not built in a narrow bank (PLL demods are a later row)", mode);
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    if (ctl_[ch].mode != mode) am_list_dirty_ = true;
+    ctl_[ch].mode = mode;
+    return 0;
+}
+
+int Receiver::set_bandpass(uint32_t ch, double lo, double hi)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the WFM branch has no band-pass (receiver.cpp:854-901)");
+    std::lock_guard<std::mutex> g(mu_);
+    ChanCtl &c = ctl_[ch];
+    const double flo = (double)(float)lo, fhi = (double)(float)hi;  // setBandPass(float, float), bandpassfilter.cpp:38
+    if (c.mode == PEBBLEGPU_DM_AM) {  // Demod::setBandwidth only acts in AM (demod.cpp:230-239)
+        c.am_bw = hi - lo;
+        c.am_dirty = true;
+    }
+    if (c.bp_valid && flo == c.lo && fhi == c.hi) return 0;  // "return if no changes", fastfir.cpp:195-199
+    c.lo = flo;  // stored before the sanity check, fastfir.cpp:200-203
+    c.hi = fhi;
+    c.bp_valid = true;
+    const double rate = (double)demod_rate_int;
+    if (flo >= fhi || flo >= rate / 2.0 || flo <= -rate / 2.0 || fhi >= rate / 2.0 || fhi <= -rate / 2.0)
+        return fail(PEBBLEGPU_E_FILTER_PARAM, "Filter Parameter error: lo %.1f hi %.1f rate %.1f", flo, fhi, rate);
+    c.bp_dirty = true;
+    return 0;
+}
+
+int Receiver::apply_controls()
+{
+    if (int rc = osc_.upload(stream_)) return rc;
+    if (wfm) return 0;
+    for (uint32_t ch = 0; ch < C; ch++) {
+        ChanCtl &c = ctl_[ch];
+        if (c.bp_dirty) {
+            bool ok = false;
+            if (int rc = ff_.design(stream_, ch, c.lo, c.hi, 0.0, (double)demod_rate_int, &ok)) return rc;
+            c.bp_dirty = false;
+        }
+        if (c.am_dirty && c.mode == PEBBLEGPU_DM_AM) {
+            if (int rc = am_.set_bandwidth(stream_, ch, c.am_bw)) return rc;
+            c.am_dirty = false;
+        }
+    }
+    if (am_list_dirty_) {
+        std::vector<int> l;
+        for (uint32_t ch = 0; ch < C; ch++) if (ctl_[ch].mode == PEBBLEGPU_DM_AM) l.push_back((int)ch);
+        if (int rc = am_.set_list(stream_, l)) return rc;
+        am_list_dirty_ = false;
+    }
+    return 0;
+}
+
+int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    PG_HIP(hipSetDevice(device));
+    if (!d_iq || n == 0) return fail(PEBBLEGPU_E_INVALID, "null input or zero samples");
+    if (with_chain && (n % superframe != 0 || n / superframe > max_sf))
+        return fail(PEBBLEGPU_E_SIZE, "n_samples %llu is not 1..%u super-frames of %llu", (unsigned long long)n, max_sf,
+                    (unsigned long long)superframe);
+    if (with_spectrum && (!bins || n % nf != 0 || n > (uint64_t)max_sf * superframe))
+        return fail(PEBBLEGPU_E_SIZE, "spectrum needs whole frames of %u samples within capacity", nf);
+    if (int rc = apply_controls()) return rc;
+    const long long in_pitch = (long long)n;
+    PG_HIP(hipEventRecord(tm.ev[0], stream_));
+    if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
+        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
+        last_spec_frames = n / nf;
+    }
+    PG_HIP(hipEventRecord(tm.ev[1], stream_));
+    if (!with_chain) {
+        for (int i = 2; i <= 6; i++) PG_HIP(hipEventRecord(tm.ev[i], stream_));
+        return 0;
+    }
+    // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
+    if (int rc = dec_.run(stream_, d_iq, in_pitch, shared_input, (long long)n, osc_, tm.ev[2])) return rc;
+    PG_HIP(hipEventRecord(tm.ev[3], stream_));
+    const long long nd = dec_.out_len();
+    if (!wfm) {
+        if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
+        PG_HIP(hipEventRecord(tm.ev[4], stream_));
+        // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
+        if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
+    } else {
+        PG_HIP(hipEventRecord(tm.ev[4], stream_));
+        if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
+    }
+    PG_HIP(hipEventRecord(tm.ev[5], stream_));
+    if (int rc = dec_.save_tails(stream_)) return rc;
+    PG_HIP(hipEventRecord(tm.ev[6], stream_));
+    osc_.advance(n);
+    last_audio_n = (uint64_t)nd;
+    return 0;
+}
+
+int Receiver::sync()
+{
+    PG_HIP(hipSetDevice(device));
+    PG_HIP(hipStreamSynchronize(stream_));
+    return 0;
+}
+
+// CB_ProcessIQData shape: one frame in; audio appears once a whole super-frame has been collected, exactly where
+// the reference stops returning early (receiver.cpp:922-931).
+int Receiver::process_iq(const double *iq, uint16_t n, double *audio_out, uint32_t *n_audio, double *spectrum_db)
+{
+    if (!iq || !n_audio) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    if (n != nf) return fail(PEBBLEGPU_E_SIZE, "process_iq takes frames of %u samples", nf);
+    if (S != 1) return fail(PEBBLEGPU_E_UNSUPPORTED, "process_iq feeds one stream; this bank has %u", S);
+    PG_HIP(hipSetDevice(device));
+    if (!d_stage_in_) PG_HIP(hipMalloc((void **)&d_stage_in_, sizeof(float2) * superframe));
+    h_frame_.resize((size_t)nf * 2);
+    for (size_t i = 0; i < (size_t)nf * 2; i++) h_frame_[i] = (float)iq[i];
+    float2 *dst = d_stage_in_ + acc_frames_ * nf;
+    PG_HIP(hipMemcpy(dst, h_frame_.data(), sizeof(float2) * nf, hipMemcpyHostToDevice));
+    *n_audio = 0;
+    if (spectrum_db && bins) {
+        if (int rc = process(dst, nf, true, false)) return rc;
+        if (int rc = sync()) return rc;
+        h_out_.resize(bins);
+        PG_HIP(hipMemcpy(h_out_.data(), d_spec, sizeof(float) * bins, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < bins; i++) spectrum_db[i] = (double)h_out_[i];
+    }
+    acc_frames_++;
+    if (acc_frames_ * nf >= superframe) {
+        acc_frames_ = 0;
+        if (int rc = process(d_stage_in_, superframe, false, true)) return rc;
+        if (int rc = sync()) return rc;
+        const size_t na = (size_t)last_audio_n;
+        h_out_.resize(na * 2);
+        PG_HIP(hipMemcpy(h_out_.data(), audio.data(0), sizeof(float2) * na, hipMemcpyDeviceToHost));
+        if (audio_out)
+            for (size_t i = 0; i < na * 2; i++) audio_out[i] = (double)h_out_[i];
+        *n_audio = (uint32_t)na;
+    }
+    return 0;
+}
+
+}  // namespace pg

@@ -1,0 +1,399 @@
+// steps.hip -- stand-alone process steps with the reference's per-class call shapes (host doubles in/out).
+// Each wraps one device core with C = 1; see include/pebblegpu.h for the interface each entry point replaces.
+#include <cmath>
+#include <new>
+#include "receiver.h"
+
+namespace pg {
+int run_mixer(hipStream_t s, const float2 *d_in, float2 *d_out, long long n, const OscBank &osc);
+
+struct StepBase {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<float> hf;   // float staging
+    std::vector<double> hd;  // double result buffer (valid until the next call, like ProcessStep::out)
+    int open(int dev)
+    {
+        device = dev;
+        PG_HIP(hipSetDevice(device));
+        PG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return 0;
+    }
+    void close_stream()
+    {
+        if (stream) {
+            (void)hipSetDevice(device);
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+            stream = nullptr;
+        }
+    }
+    int up(float2 *dst, const double *src, size_t n)
+    {
+        hf.resize(n * 2);
+        for (size_t i = 0; i < n * 2; i++) hf[i] = (float)src[i];
+        PG_HIP(hipMemcpyAsync(dst, hf.data(), sizeof(float2) * n, hipMemcpyHostToDevice, stream));
+        PG_HIP(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int down(double *dst, const float2 *src, size_t n)
+    {
+        hf.resize(n * 2);
+        PG_HIP(hipStreamSynchronize(stream));
+        PG_HIP(hipMemcpy(hf.data(), src, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n * 2; i++) dst[i] = (double)hf[i];
+        return 0;
+    }
+};
+}  // namespace pg
+
+using pg::fail;
+
+struct pebblegpu_mixer : pg::StepBase {
+    uint32_t n = 0;
+    pg::OscBank osc;
+    float2 *d_in = nullptr, *d_out = nullptr;
+};
+struct pebblegpu_decimator : pg::StepBase {
+    uint32_t fs = 0, cap = 0;
+    bool built = false;
+    pg::OscBank osc;  // frequency 0: the oscillator is bypassed, the fused kernel only decimates
+    pg::DecimCore dec;
+    float2 *d_in = nullptr;
+};
+struct pebblegpu_fastfir : pg::StepBase {
+    pg::FastFirCore ff;
+    pg::HistBuf in;
+    float2 *d_out = nullptr;
+    long long cap = 0;
+    std::vector<double> pend;  // samples waiting for a whole block (m_InBufInPos - (FIR-1))
+    double lo = -1.0, hi = 1.0, offset = 1.0, rate = 1.0;  // fastfir.cpp:141-144
+};
+struct pebblegpu_demod : pg::StepBase {
+    int mode = PEBBLEGPU_DM_AM;
+    uint32_t cap = 0;
+    pg::AmCore am;
+    pg::WfmCore wfm;
+    float2 *d_in = nullptr, *d_out = nullptr;
+};
+struct pebblegpu_spectrum : pg::StepBase {
+    pg::SpectrumCore sp;
+    float2 *d_in = nullptr;
+    float *d_out = nullptr;
+    std::vector<float> hs;
+};
+
+extern "C" {
+
+static int step_device(int device)
+{
+    int n = pebblegpu_device_count();
+    if (n <= 0) return fail(PEBBLEGPU_E_NO_DEVICE, "no HIP device visible: libpebblegpu has no CPU path");
+    if (device < 0 || device >= n) return fail(PEBBLEGPU_E_INVALID, "device %d out of range", device);
+    return 0;
+}
+
+// ---------------- Mixer ----------------
+int pebblegpu_mixer_create(int device, uint32_t sample_rate, uint32_t buffer_size, pebblegpu_mixer **out)
+{
+    if (!out || !buffer_size || !sample_rate) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = step_device(device)) return rc;
+    pebblegpu_mixer *m = new (std::nothrow) pebblegpu_mixer();
+    if (!m) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    m->n = buffer_size;
+    int rc = m->open(device);
+    if (!rc) rc = m->osc.init(1, (double)sample_rate);
+    if (!rc && hipMalloc((void **)&m->d_in, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (!rc && hipMalloc((void **)&m->d_out, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (rc) { pebblegpu_mixer_destroy(m); return rc; }
+    m->hd.resize((size_t)buffer_size * 2);
+    m->osc.retune(0, 0.0);  // ctor: setFrequency(0), mixer.cpp:13
+    *out = m;
+    return 0;
+}
+int pebblegpu_mixer_destroy(pebblegpu_mixer *m)
+{
+    if (!m) return 0;
+    m->close_stream();
+    m->osc.release();
+    if (m->d_in) (void)hipFree(m->d_in);
+    if (m->d_out) (void)hipFree(m->d_out);
+    delete m;
+    return 0;
+}
+int pebblegpu_mixer_set_frequency(pebblegpu_mixer *m, double f)
+{
+    if (!m) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    m->osc.retune(0, f);
+    return 0;
+}
+int pebblegpu_mixer_process(pebblegpu_mixer *m, const double *in, const double **out)
+{
+    if (!m || !in || !out) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    if ((-m->osc.ctl[0].freq) == 0) { *out = in; return 0; }  // mixer.cpp:51-53
+    PG_HIP(hipSetDevice(m->device));
+    if (int rc = m->osc.upload(m->stream)) return rc;
+    if (int rc = m->up(m->d_in, in, m->n)) return rc;
+    if (int rc = pg::run_mixer(m->stream, m->d_in, m->d_out, (long long)m->n, m->osc)) return rc;
+    if (int rc = m->down(m->hd.data(), m->d_out, m->n)) return rc;
+    m->osc.advance(m->n);
+    *out = m->hd.data();
+    return 0;
+}
+
+// ---------------- Decimator ----------------
+int pebblegpu_decimator_create(int device, uint32_t sample_rate, uint32_t buffer_size, pebblegpu_decimator **out)
+{
+    if (!out || !buffer_size || !sample_rate) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = step_device(device)) return rc;
+    pebblegpu_decimator *d = new (std::nothrow) pebblegpu_decimator();
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    d->fs = sample_rate;
+    d->cap = buffer_size;
+    int rc = d->open(device);
+    if (!rc) rc = d->osc.init(1, (double)sample_rate);
+    if (!rc && hipMalloc((void **)&d->d_in, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (rc) { pebblegpu_decimator_destroy(d); return rc; }
+    d->osc.retune(0, 0.0);
+    *out = d;
+    return 0;
+}
+int pebblegpu_decimator_destroy(pebblegpu_decimator *d)
+{
+    if (!d) return 0;
+    d->close_stream();
+    d->osc.release();
+    d->dec.release();
+    if (d->d_in) (void)hipFree(d->d_in);
+    delete d;
+    return 0;
+}
+int pebblegpu_decimator_build_chain(pebblegpu_decimator *d, uint32_t sample_rate_in, uint32_t protect_bw, uint32_t sample_rate_out,
+                                    float *achieved_rate)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    PG_HIP(hipSetDevice(d->device));
+    const pg::design::Chain c = pg::design::build_chain(sample_rate_in, protect_bw, sample_rate_out);
+    if (achieved_rate) *achieved_rate = c.rate;
+    d->built = false;
+    if (c.stages.empty()) { d->dec.release(); d->dec.chain = c; return 0; }  // "No decimation, just return" (decimator.cpp:155-160)
+    if (c.stages.size() > (size_t)pg::kMaxStages) return fail(PEBBLEGPU_E_UNSUPPORTED, "chain too long");
+    if (int rc = d->dec.init(1, c, (long long)d->cap, 0, 1.0f)) return rc;
+    d->built = true;
+    return 0;
+}
+int pebblegpu_decimator_dec_by2_stages(const pebblegpu_decimator *d, uint32_t *stages)
+{
+    if (!d || !stages) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    *stages = d->dec.chain.dec_by2;
+    return 0;
+}
+int pebblegpu_decimator_process(pebblegpu_decimator *d, const double *in, double *out, uint32_t n, uint32_t *n_out)
+{
+    if (!d || !in || !out || !n_out) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    if (!d->built) {  // empty chain: copy through
+        memcpy(out, in, sizeof(double) * 2 * n);
+        *n_out = n;
+        return 0;
+    }
+    if (n > d->cap) return fail(PEBBLEGPU_E_SIZE, "%u samples exceed bufferSize %u", n, d->cap);
+    PG_HIP(hipSetDevice(d->device));
+    if (int rc = d->osc.upload(d->stream)) return rc;
+    if (int rc = d->up(d->d_in, in, n)) return rc;
+    if (int rc = d->dec.run(d->stream, d->d_in, (long long)n, false, (long long)n, d->osc)) return rc;
+    const long long no = d->dec.out_len();
+    if (int rc = d->down(out, d->dec.out().data(), (size_t)no)) return rc;
+    if (int rc = d->dec.save_tails(d->stream)) return rc;
+    PG_HIP(hipStreamSynchronize(d->stream));
+    *n_out = (uint32_t)no;
+    return 0;
+}
+
+// ---------------- CFastFIR ----------------
+int pebblegpu_fastfir_create(int device, uint32_t fft_size, uint32_t fir_size, pebblegpu_fastfir **out)
+{
+    if (!out) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    if (int rc = step_device(device)) return rc;
+    pebblegpu_fastfir *f = new (std::nothrow) pebblegpu_fastfir();
+    if (!f) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    int rc = f->open(device);
+    if (!rc) rc = f->ff.init(1, fft_size ? fft_size : 2048, fir_size ? fir_size : 1025);
+    if (!rc) {
+        f->cap = 64 * f->ff.block_len();
+        rc = f->in.alloc(1, (int)f->ff.taps - 1, f->cap);
+    }
+    if (!rc && hipMalloc((void **)&f->d_out, sizeof(float2) * (size_t)f->cap) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (rc) { pebblegpu_fastfir_destroy(f); return rc; }
+    *out = f;
+    return 0;
+}
+int pebblegpu_fastfir_destroy(pebblegpu_fastfir *f)
+{
+    if (!f) return 0;
+    f->close_stream();
+    f->ff.release();
+    f->in.release();
+    if (f->d_out) (void)hipFree(f->d_out);
+    delete f;
+    return 0;
+}
+int pebblegpu_fastfir_setup(pebblegpu_fastfir *f, double lo, double hi, double offset, double rate)
+{
+    if (!f) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    if (lo == f->lo && hi == f->hi && offset == f->offset && rate == f->rate) return 0;  // fastfir.cpp:195-199
+    f->lo = lo; f->hi = hi; f->offset = offset; f->rate = rate;
+    PG_HIP(hipSetDevice(f->device));
+    bool ok = false;
+    if (int rc = f->ff.design(f->stream, 0, lo, hi, offset, rate, &ok)) return rc;
+    if (!ok) return fail(PEBBLEGPU_E_FILTER_PARAM, "Filter Parameter error");
+    return 0;
+}
+int pebblegpu_fastfir_process(pebblegpu_fastfir *f, int n, const double *in, double *out, int *n_out)
+{
+    if (!f || !n_out || (n > 0 && (!in || !out))) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    *n_out = 0;
+    if (n <= 0) return 0;
+    PG_HIP(hipSetDevice(f->device));
+    f->pend.insert(f->pend.end(), in, in + (size_t)n * 2);
+    const long long L = f->ff.block_len();
+    long long avail = (long long)(f->pend.size() / 2), done = 0;
+    while (avail - done >= L) {
+        long long take = ((avail - done) / L) * L;
+        if (take > f->cap) take = f->cap;
+        if (int rc = f->up(f->in.data(), f->pend.data() + done * 2, (size_t)take)) return rc;
+        if (int rc = f->ff.run(f->stream, f->in, take, f->d_out, take)) return rc;
+        if (int rc = f->down(out + (size_t)(*n_out) * 2, f->d_out, (size_t)take)) return rc;
+        // overlap for the next block = last taps-1 inputs (m_pFFTOverlapBuf)
+        const int hist = f->in.hist;
+        if (take >= hist) {
+            PG_HIP(hipMemcpyAsync(f->in.data() - hist, f->in.data() + take - hist, sizeof(float2) * hist, hipMemcpyDeviceToDevice, f->stream));
+        } else {  // FIR longer than one block: shift what is kept, then append
+            PG_HIP(hipMemcpyAsync(f->in.data() - hist, f->in.data() - hist + take, sizeof(float2) * (hist - take), hipMemcpyDeviceToDevice, f->stream));
+            PG_HIP(hipMemcpyAsync(f->in.data() - take, f->in.data(), sizeof(float2) * take, hipMemcpyDeviceToDevice, f->stream));
+        }
+        PG_HIP(hipStreamSynchronize(f->stream));
+        done += take;
+        *n_out += (int)take;
+    }
+    f->pend.erase(f->pend.begin(), f->pend.begin() + (size_t)done * 2);
+    return 0;
+}
+
+// ---------------- Demod ----------------
+int pebblegpu_demod_create(int device, uint32_t sample_rate, uint32_t wfm_sample_rate, uint32_t buffer_size, pebblegpu_demod **out)
+{
+    if (!out || !buffer_size) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = step_device(device)) return rc;
+    pebblegpu_demod *d = new (std::nothrow) pebblegpu_demod();
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    d->cap = buffer_size;
+    int rc = d->open(device);
+    if (!rc && sample_rate) rc = d->am.init(1, (double)sample_rate, buffer_size);
+    if (!rc && sample_rate) {
+        rc = d->am.set_bandwidth(d->stream, 0, 16000);  // Demod_AM ctor, demod_am.cpp:9
+        if (!rc) rc = d->am.set_list(d->stream, std::vector<int>(1, 0));
+    }
+    if (!rc && wfm_sample_rate) rc = d->wfm.init(1, (double)wfm_sample_rate, buffer_size);
+    if (!rc && hipMalloc((void **)&d->d_in, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (!rc && hipMalloc((void **)&d->d_out, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (rc) { pebblegpu_demod_destroy(d); return rc; }
+    d->hd.resize((size_t)buffer_size * 2);
+    *out = d;
+    return 0;
+}
+int pebblegpu_demod_destroy(pebblegpu_demod *d)
+{
+    if (!d) return 0;
+    d->close_stream();
+    d->am.release();
+    d->wfm.release();
+    if (d->d_in) (void)hipFree(d->d_in);
+    if (d->d_out) (void)hipFree(d->d_out);
+    delete d;
+    return 0;
+}
+int pebblegpu_demod_set_mode(pebblegpu_demod *d, int mode)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    if (mode < 0 || mode > PEBBLEGPU_DM_NONE) return fail(PEBBLEGPU_E_INVALID, "bad mode %d", mode);
+    if (mode == PEBBLEGPU_DM_SAM || mode == PEBBLEGPU_DM_FMN || mode == PEBBLEGPU_DM_FMS)
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d (PLL / stereo) is a later row", mode);
+    if (mode == PEBBLEGPU_DM_AM && d->am.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a narrow sample rate");
+    if (mode == PEBBLEGPU_DM_FMM && d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
+    d->mode = mode;
+    return 0;
+}
+int pebblegpu_demod_set_bandwidth(pebblegpu_demod *d, double bw)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    if (d->mode != PEBBLEGPU_DM_AM) return 0;  // demod.cpp:230-239
+    PG_HIP(hipSetDevice(d->device));
+    return d->am.set_bandwidth(d->stream, 0, bw);
+}
+int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const double **out)
+{
+    if (!d || !in || !out || n <= 0) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (d->mode != PEBBLEGPU_DM_AM && d->mode != PEBBLEGPU_DM_FMM) { *out = in; return 0; }  // demod.cpp:127-138
+    if ((uint32_t)n > d->cap) return fail(PEBBLEGPU_E_SIZE, "%d samples exceed bufferSize %u", n, d->cap);
+    PG_HIP(hipSetDevice(d->device));
+    if (int rc = d->up(d->d_in, in, (size_t)n)) return rc;
+    int rc;
+    if (d->mode == PEBBLEGPU_DM_AM) rc = d->am.run(d->stream, d->d_in, n, d->d_out, n, n);
+    else rc = d->wfm.run(d->stream, d->d_in, n, d->d_out, n, n);
+    if (rc) return rc;
+    if (int rc2 = d->down(d->hd.data(), d->d_out, (size_t)n)) return rc2;
+    *out = d->hd.data();
+    return 0;
+}
+
+// ---------------- Spectrum ----------------
+int pebblegpu_spectrum_create(int device, uint32_t fft_size, double sample_rate, uint32_t samples_per_buffer, pebblegpu_spectrum **out)
+{
+    (void)sample_rate;  // only feeds the bin width in the reference (fft.cpp:81)
+    if (!out || fft_size == 0) return fail(PEBBLEGPU_E_INVALID, "bad argument");  // "if (_fftSize == 0) return; //Error"
+    if (int rc = step_device(device)) return rc;
+    pebblegpu_spectrum *s = new (std::nothrow) pebblegpu_spectrum();
+    if (!s) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    int rc = s->open(device);
+    if (!rc) rc = s->sp.init(1, samples_per_buffer, fft_size);
+    if (!rc && hipMalloc((void **)&s->d_in, sizeof(float2) * samples_per_buffer) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (!rc && hipMalloc((void **)&s->d_out, sizeof(float) * s->sp.bins) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (rc) { pebblegpu_spectrum_destroy(s); return rc; }
+    *out = s;
+    return 0;
+}
+int pebblegpu_spectrum_destroy(pebblegpu_spectrum *s)
+{
+    if (!s) return 0;
+    s->close_stream();
+    s->sp.release();
+    if (s->d_in) (void)hipFree(s->d_in);
+    if (s->d_out) (void)hipFree(s->d_out);
+    delete s;
+    return 0;
+}
+int pebblegpu_spectrum_bins(const pebblegpu_spectrum *s, uint32_t *bins)
+{
+    if (!s || !bins) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    *bins = s->sp.bins;
+    return 0;
+}
+int pebblegpu_spectrum_process(pebblegpu_spectrum *s, const double *in, int n, double *out_db, int *overload)
+{
+    if (!s || !in || !out_db) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    if ((uint32_t)n != s->sp.nf)
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "only the windowed case numSamples == samplesPerBuffer (%u) is built (fft.cpp:132)", s->sp.nf);
+    PG_HIP(hipSetDevice(s->device));
+    int ov = 0;  // m_isOverload: any |re| or |im| above m_overLimit = 0.9 (fft.cpp:137-140), flagged on the host copy
+    for (int i = 0; i < 2 * n; i++) if (std::fabs(in[i]) > 0.9) { ov = 1; break; }
+    if (int rc = s->up(s->d_in, in, (size_t)n)) return rc;
+    if (int rc = s->sp.run(s->stream, s->d_in, n, 1, s->d_out)) return rc;
+    PG_HIP(hipStreamSynchronize(s->stream));
+    s->hs.resize(s->sp.bins);
+    PG_HIP(hipMemcpy(s->hs.data(), s->d_out, sizeof(float) * s->sp.bins, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < s->sp.bins; i++) out_db[i] = (double)s->hs[i];
+    if (overload) *overload = ov;
+    return 0;
+}
+
+}  // extern "C"

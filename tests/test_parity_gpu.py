@@ -1,0 +1,444 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): time-domain rel-RMS <= 1e-5 on >= 3 output frames including the first
+(transients); spectrum max |dB| <= 0.1 over bins the oracle puts above -110 dB, from frame 1 on (frame 0
+averages with an uninitialised buffer in the reference, fft.cpp:107-115; both sides here start it at zero).
+The device computes in fp32 (fp64 only in recurrences and the oscillator phase); typical error is ~1e-7.
+"""
+import numpy as np
+import pytest
+
+from tests.signals import lcg_noise, tones
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+TOL_DB = 0.1
+
+
+def rel_rms(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2)) / max(np.sqrt(np.mean(np.abs(b) ** 2)), 1e-12))
+
+
+def db_err(g, r):
+    m = r > -110
+    return float(np.abs(g - r)[m].max())
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone steps (reference class shapes)
+# ------------------------------------------------------------------------------------------------
+def test_mixer_step_with_retune(gpu_lib, oracle_mod):
+    """Mixer::processBlock incl. the start-up amplitude transient, state across frames and a mid-stream retune."""
+    import pebblesdr_amd as P
+    fs = 2.048e6
+    x = tones(fs, 6 * 2048, [(0.5, 100e3), (0.2, -300e3)]) + lcg_noise(6 * 2048, 2, 1e-3)
+    ref, mx = oracle_mod.Mixer(fs), P.Mixer(fs, 2048)
+    for f in range(6):
+        if f == 0:
+            ref.set_frequency(100e3); mx.setFrequency(100e3)
+        if f == 3:
+            ref.set_frequency(-250e3); mx.setFrequency(-250e3)
+        fr = x[f * 2048:(f + 1) * 2048]
+        assert rel_rms(mx.processBlock(fr), ref.process(fr)) <= TOL
+    # f == 0 returns the input untouched (mixer.cpp:51-53)
+    mx.setFrequency(0)
+    fr = x[:2048].copy()
+    assert mx.processBlock(fr) is fr
+
+
+@pytest.mark.parametrize("fs,bw,n", [(2048000, 30000, 2048), (2048000, 200000, 2048), (20000000, 200000, 2048),
+                                     (20000000, 30000, 16384), (100000000, 30000, 49152)])
+def test_decimator_step(gpu_lib, oracle_mod, fs, bw, n):
+    """Decimator::process on every chain SURVEY.md 8(a-3) lists that fits one frame without the reference's fallback."""
+    import pebblesdr_amd as P
+    x = tones(fs, 4 * n, [(0.5, 1000.0), (0.3, fs / 5), (0.1, -fs / 3)]) + lcg_noise(4 * n, 3, 1e-2)
+    ref = oracle_mod.Decimator(fs, bw)
+    d = P.Decimator(fs, n)
+    assert d.buildDecimationChain(fs, bw) == ref.rate
+    assert d.decBy2Stages() == ref.dec_by2_stages
+    for f in range(4):
+        fr = x[f * n:(f + 1) * n]
+        r, g = ref.process(fr), d.process(fr)
+        assert len(r) == len(g)
+        assert rel_rms(g, r) <= TOL
+
+
+def test_decimator_short_frame_is_an_error_not_a_degraded_filter(gpu_lib):
+    """Where the reference silently drops to unfiltered sample skipping (decimator.cpp:602-625) the library refuses."""
+    import pebblesdr_amd as P
+    d = P.Decimator(20000000, 2048)
+    d.buildDecimationChain(20000000, 30000)
+    with pytest.raises(P.PebbleGpuError) as e:
+        d.process(np.zeros(2048, dtype=complex))
+    assert e.value.code == -5
+
+
+@pytest.mark.parametrize("fft,taps,lo,hi", [(2048, 1025, 300, 3000), (2048, 1025, -5000, 5000), (2048, 1025, -3000, -300),
+                                            (2048, 1025, 1000, 1500), (8192, 4097, -5000, 5000), (4096, 2049, 300, 3000)])
+def test_fastfir_step(gpu_lib, oracle_mod, fft, taps, lo, hi):
+    import pebblesdr_amd as P
+    n = 2048
+    x = tones(64000, 8 * n, [(0.4873, 1000.0), (0.3, -12000.0), (0.2, 1250.0)]) + lcg_noise(8 * n, 4, 1e-3)
+    ref = oracle_mod.FastFIR(fft, taps)
+    ref.setup(lo, hi, 0, 64000)
+    f = P.FastFIR(fft, taps)
+    f.SetupParameters(lo, hi, 0, 64000)
+    got_any = 0
+    for k in range(8):
+        fr = x[k * n:(k + 1) * n]
+        r, g = ref.process(fr), f.ProcessData(fr)
+        assert len(r) == len(g)
+        if len(r):
+            got_any += 1
+            assert rel_rms(g, r) <= TOL
+    assert got_any >= 3
+    # invalid parameters: error code, previous taps stay active (fastfir.cpp:208-216)
+    with pytest.raises(P.PebbleGpuError) as e:
+        f.SetupParameters(3000, 300, 0, 64000)
+    assert e.value.code == -4
+    ref.setup(3000, 300, 0, 64000)
+    fr = x[:n]
+    r, g = ref.process(fr), f.ProcessData(fr)
+    assert len(r) == len(g) and (len(r) == 0 or rel_rms(g, r) <= TOL)
+
+
+def test_fastfir_ragged_input_lengths(gpu_lib, oracle_mod):
+    """ProcessData accepts any InLength; output count follows whole FFT blocks (fastfir.cpp:281-319)."""
+    import pebblesdr_amd as P
+    x = lcg_noise(7000, 8, 0.5)
+    ref = oracle_mod.FastFIR(); ref.setup(-5000, 5000, 0, 64000)
+    f = P.FastFIR(); f.SetupParameters(-5000, 5000, 0, 64000)
+    off = 0
+    R, G = [], []
+    for ln in (1, 1023, 1, 500, 3000, 2475):
+        r, g = ref.process(x[off:off + ln]), f.ProcessData(x[off:off + ln])
+        assert len(r) == len(g)
+        R.append(r); G.append(g)
+        off += ln
+    assert rel_rms(np.concatenate(G), np.concatenate(R)) <= TOL
+
+
+def test_am_demod_step(gpu_lib, oracle_mod):
+    import pebblesdr_amd as P
+    n = 2048
+    t = np.arange(6 * n) / 64000.0
+    am = (0.3 * (1 + 0.5 * np.cos(2 * np.pi * 1000 * t) + 0.2 * np.cos(2 * np.pi * 3300 * t))) * np.exp(0.7j) + lcg_noise(6 * n, 5, 1e-4)
+    ref = oracle_mod.DemodAM(64000, 10000)
+    d = P.Demod(64000, 256000, n)
+    d.setDemodMode(P.DM_AM)
+    d.setBandwidth(10000)
+    for k in range(6):
+        fr = am[k * n:(k + 1) * n]
+        if k == 4:  # re-design mid-stream: CFir::InitLPFilter also clears the delay line
+            ref.set_bandwidth(6000); d.setBandwidth(6000)
+        assert rel_rms(d.processBlock(fr), ref.process(fr)) <= TOL
+    # pass-through modes hand back the input pointer (demod.cpp:127-138)
+    d.setDemodMode(P.DM_USB)
+    fr = am[:n].copy()
+    assert d.processBlock(fr) is fr
+
+
+@pytest.mark.parametrize("fsw", [256000, 312500, 390625])
+def test_wfm_mono_demod_step(gpu_lib, oracle_mod, fsw):
+    """processDataMono at the three WFM rates SURVEY.md 8(a-3) lists; the last call is long enough to run the
+    chunk-parallel (warm-up) scan path across several workgroups, with a ragged tail."""
+    import pebblesdr_amd as P
+    n = 2048
+    tw = np.arange(15 * n) / fsw
+    fm = 0.5 * np.exp(1j * (75000 / 1000.0) * np.sin(2 * np.pi * 1000 * tw)) + lcg_noise(15 * n, 6, 1e-4)
+    ref = oracle_mod.DemodWFM(fsw)
+    d = P.Demod(64000, fsw, 12 * n)
+    d.setDemodMode(P.DM_FMM)
+    off = 0
+    for ln in (n, n, 3 * n, 10 * n - 100):
+        fr = fm[off:off + ln]
+        assert rel_rms(d.processBlock(fr), ref.process(fr)) <= TOL
+        off += ln
+
+
+@pytest.mark.parametrize("bins", [2048, 4096, 8192])
+def test_spectrum_step(gpu_lib, oracle_mod, bins):
+    """fftSpectrum: window, pruned zero-pad FFT, unfold, previous-frame averaging, dB, clip."""
+    import pebblesdr_amd as P
+    fs = 2.048e6
+    x = tones(fs, 4 * 2048, [(10 ** (-10 / 20), 123456.7), (10 ** (-40 / 20), -700001.3)]) + lcg_noise(4 * 2048, 1, 1e-4)
+    ref = oracle_mod.Spectrum(bins, 2048)
+    sp = P.Spectrum(bins, fs, 2048)
+    assert sp.bins == bins
+    for f in range(4):
+        fr = x[f * 2048:(f + 1) * 2048]
+        r = ref.process(fr)
+        g, ov = sp.fftSpectrum(fr)
+        assert not ov
+        assert db_err(g, r) <= TOL_DB
+        assert g.min() >= -120.0 and g.max() <= 0.0
+    _, ov = sp.fftSpectrum(np.full(2048, 0.95 + 0j))
+    assert ov  # m_overLimit = 0.9, fft.cpp:137-140
+
+
+def test_spectrum_known_answer_on_device(gpu_lib):
+    """The reference's own table (fft.cpp:363-369) straight from the device: -10 dB tone at 48 kHz / 1 Msps."""
+    import pebblesdr_amd as P
+    x = tones(1e6, 2 * 2048, [(10 ** (-10 / 20), 48000.0)])
+    for bins, want in ((2048, -10.3044), (4096, -10.1264), (8192, -10.0096)):
+        sp = P.Spectrum(bins, 1e6, 2048)
+        sp.fftSpectrum(x[:2048])
+        g, _ = sp.fftSpectrum(x[2048:])
+        assert abs(g.max() - want) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# the receiver bank (Receiver::processIQData)
+# ------------------------------------------------------------------------------------------------
+def test_config1_am_host_frame_path(gpu_lib, oracle_mod):
+    """BASELINE config 1 shape: 2.048 Msps, 1 channel, AM, through the CB_ProcessIQData-shaped host path, with the
+    stock 2048/1025 FastFIR; spectrum 4096 bins every frame; 3 audio frames incl. the first."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    ref = oracle_mod.Receiver(fs, n, 4096)
+    ref.set_mode(oracle_mod.AM); ref.set_mixer(100e3); ref.set_filter(-5000, 5000)
+    rx = P.ReceiverBank(fs, 1, True, False, 4096)
+    rx.set_mode(0, P.DM_AM); rx.set_mixer(0, 100e3); rx.set_bandpass(0, -5000, 5000)
+    nfr = 3 * 32
+    t = np.arange(nfr * n) / fs
+    x = 10 ** (-10 / 20) * (1 + 0.5 * np.cos(2 * np.pi * 1000 * t)) * np.exp(2j * np.pi * 100e3 * t) + lcg_noise(nfr * n, 1, 3e-4)
+    x = np.round(x * 32767.0) / 32767.0  # 16-bit PCM WAV scaling, wavfile.cpp:299-300
+    audio_frames = 0
+    for f in range(nfr):
+        fr = x[f * n:(f + 1) * n]
+        ra, rs = ref.process(fr)
+        ga, gs = rx.process_iq(fr, want_spectrum=(f < 4))
+        assert len(ra) == len(ga)
+        if 1 <= f < 4:
+            assert db_err(gs, rs) <= TOL_DB
+        if len(ra):
+            audio_frames += 1
+            assert rel_rms(ga, ra) <= TOL
+    assert audio_frames == 3
+
+
+def test_config1_variant_8192_fastfir(gpu_lib, oracle_mod):
+    """Config 1's '4096-tap' band-pass = the parametrised 8192/4097 FastFIR: audio comes out 4096 at a time."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    ref = oracle_mod.Receiver(fs, n, 0, 8192, 4097)
+    ref.set_mode(oracle_mod.AM); ref.set_mixer(100e3); ref.set_filter(-5000, 5000)
+    rx = P.ReceiverBank(fs, 1, True, False, 0, fastfir_fft=8192, fastfir_taps=4097)
+    rx.set_mode(0, P.DM_AM); rx.set_mixer(0, 100e3); rx.set_bandpass(0, -5000, 5000)
+    nfr = 6 * 32
+    t = np.arange(nfr * n) / fs
+    x = 0.3 * (1 + 0.5 * np.cos(2 * np.pi * 1000 * t)) * np.exp(2j * np.pi * 100e3 * t) + lcg_noise(nfr * n, 1, 3e-4)
+    got = 0
+    for f in range(nfr):
+        fr = x[f * n:(f + 1) * n]
+        ra, _ = ref.process(fr, want_spectrum=False)
+        ga, _ = rx.process_iq(fr)
+        assert len(ra) == len(ga)
+        if len(ra):
+            got += 1
+            assert len(ra) == 4096 and rel_rms(ga, ra) <= TOL
+    assert got == 3
+
+
+def test_config2_wfm_with_spectrum(gpu_lib, oracle_mod):
+    """BASELINE config 2 (the bench workload) at parity size: 20 Msps HackRF-shape int8 IQ, 1 channel, mixer +1 MHz,
+    chain hb11x8,hb15,hb23,hb47 -> 312.5 kHz, WFM mono, 8192-bin spectrum on every 2048-sample frame.
+    The oracle runs frame size 8192 (>= every stage's taps) because the cascade is frame-invariant
+    (tests/test_oracle_pins.py::test_decimator_is_frame_invariant) and 2048 would hit the reference's fallback."""
+    import pebblesdr_amd as P
+    fs, n = 20_000_000, 2048
+    rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=4)
+    assert rx.chain() == [(11, 8), (15, 2), (23, 2), (47, 2)] and rx.D == 64 and rx.info.demod_rate == 312500.0
+    rx.set_mixer(0, 1.0e6)
+    sf = rx.superframe
+    N = 6 * sf
+    t = np.arange(N) / fs
+    x = 0.5 * np.exp(1j * (2 * np.pi * 1.0e6 * t + 75.0 * np.sin(2 * np.pi * 1000 * t))) + lcg_noise(N, 2, 1e-2)
+    x = (np.round(x.real * 128) + 1j * np.round(x.imag * 128)) / 128.0  # CPX8 * 1/128, deviceinterfacebase.cpp:648-658
+    # reference: spectrum per 2048 frame, chain per 8192 frame, demod per 2048 demod-rate samples
+    spec = oracle_mod.Spectrum(8192, 2048)
+    rs = np.array([spec.process(x[f * n:(f + 1) * n]) for f in range(N // n)])
+    mix = oracle_mod.Mixer(fs); mix.set_frequency(1.0e6)
+    dec = oracle_mod.Decimator(fs, 200000)
+    dem = oracle_mod.DemodWFM(312500)
+    z = np.concatenate([dec.process(mix.process(x[i:i + 8192])) for i in range(0, N, 8192)])
+    ra = np.concatenate([dem.process(z[i:i + 2048]) for i in range(0, len(z), 2048)])
+    ga, gs = [], []
+    for lo, hi in ((0, sf), (sf, 2 * sf), (2 * sf, 6 * sf)):  # uneven calls: 1, 1 and 4 super-frames
+        a, s = rx.process(x[lo:hi])
+        ga.append(a[0]); gs.append(s[0])
+    ga, gs = np.concatenate(ga), np.concatenate(gs)
+    assert ga.shape == ra.shape and gs.shape == rs.shape
+    for k in range(6):
+        assert rel_rms(ga[k * 2048:(k + 1) * 2048], ra[k * 2048:(k + 1) * 2048]) <= TOL
+    for f in range(1, N // n):
+        assert db_err(gs[f], rs[f]) <= TOL_DB
+
+
+def test_config3_shared_input_usb_bank(gpu_lib, oracle_mod):
+    """BASELINE config 3 at parity size: 2.048 Msps shared wideband input, 32 of the 256 USB channels
+    (f_c = -960 kHz + 7.5 kHz*c), one tone per channel pass-band + noise, 3 super-frames over 2 calls."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 32
+    chans = [8 * c for c in range(C)]
+    fcs = [-960e3 + 7.5e3 * c for c in chans]
+    rng = np.random.RandomState(3)
+    ph = rng.uniform(0, 2 * np.pi, 256)
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    refs = []
+    for i, fc in enumerate(fcs):
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fc); r.set_filter(300, 3000)
+        refs.append(r)
+        rx.set_mode(i, P.DM_USB); rx.set_mixer(i, fc); rx.set_bandpass(i, 300, 3000)
+    sf = rx.superframe
+    assert sf == 32 * 2048
+    x = tones(fs, 3 * sf, [(0.003, -960e3 + 7.5e3 * c + 1000.0 + 3.1 * c, ph[c]) for c in range(256)]) + lcg_noise(3 * sf, 3, 1e-3)
+    g = np.concatenate([rx.process(x[:sf])[0], rx.process(x[sf:])[0]], axis=1)
+    for i in range(C):
+        r = np.concatenate([refs[i].process(x[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(3 * sf // n)])
+        assert r.shape == g[i].shape
+        for k in range(3):
+            assert rel_rms(g[i][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL
+
+
+def test_config4_cic3_chain_mixed_am_usb(gpu_lib, oracle_mod):
+    """BASELINE config 4 at parity size: 100 Msps shared input, chain cic3x16,hb11x16,hb15,hb23,hb47 (D = 2048),
+    AM on even / USB on odd channels, 4 channels, 2 super-frames.  Oracle frame N = 49152 as SURVEY.md 8(d) prescribes
+    (stage inputs 3072/192/96/48 >= taps)."""
+    import pebblesdr_amd as P
+    fs, C = 100_000_000, 4
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    assert rx.chain() == [(0, 16), (11, 16), (15, 2), (23, 2), (47, 2)] and rx.D == 2048
+    fcs = [1.0e6, -7.3e6, 21.0e6, -33.5e6]
+    sf = rx.superframe  # 2048*2048
+    N = 2 * sf
+    t = np.arange(N) / fs
+    x = np.zeros(N, dtype=np.complex128)
+    for i, fc in enumerate(fcs):
+        if i % 2 == 0:
+            x += 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 800 * t)) * np.exp(2j * np.pi * fc * t)
+        else:
+            x += 0.1 * np.exp(2j * np.pi * (fc + 1200.0) * t)
+    x += lcg_noise(N, 4, 1e-3)
+    rate = int(rx.info.demod_rate_int)
+    assert rate == 48828
+    for i, fc in enumerate(fcs):
+        rx.set_mixer(i, fc)
+        if i % 2 == 0:
+            rx.set_mode(i, P.DM_AM); rx.set_bandpass(i, -5000, 5000)
+        else:
+            rx.set_mode(i, P.DM_USB); rx.set_bandpass(i, 300, 3000)
+    ga = np.concatenate([rx.process(x[:sf])[0], rx.process(x[sf:])[0]], axis=1)
+    F = 49152
+    for i, fc in enumerate(fcs):
+        mix = oracle_mod.Mixer(fs); mix.set_frequency(fc)
+        dec = oracle_mod.Decimator(fs, 30000)
+        # feed the oracle 49152-sample frames; the last frame absorbs the remainder (49152..98303 samples, a multiple
+        # of D = 2048) so that no stage ever sees fewer samples than taps
+        z = []
+        pos = 0
+        while pos < N:
+            ln = F if N - pos - F >= F else N - pos
+            z.append(dec.process(mix.process(x[pos:pos + ln])))
+            pos += ln
+        z = np.concatenate(z) * 10 ** (2 * 11 / 20.0)  # gain restore, 11 stages
+        ff = oracle_mod.FastFIR()
+        if i % 2 == 0:
+            ff.setup(-5000, 5000, 0, rate)
+            am = oracle_mod.DemodAM(rate, 10000)
+            r = np.concatenate([am.process(ff.process(z[k:k + 2048])) for k in range(0, len(z), 2048)])
+        else:
+            ff.setup(300, 3000, 0, rate)
+            r = np.concatenate([ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048)])
+        assert r.shape == ga[i].shape
+        for k in range(2):
+            assert rel_rms(ga[i][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL
+
+
+def test_independent_streams_and_retune(gpu_lib, oracle_mod):
+    """C independent streams (shared_input = 0), a retune and a band-pass change between calls, mode switch to NONE."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 3
+    rx = P.ReceiverBank(fs, C, False, False, 2048, max_superframes=1)
+    refs = [oracle_mod.Receiver(fs, n, 2048) for _ in range(C)]
+    f0 = [50e3, -200e3, 333e3]
+    for c in range(C):
+        refs[c].set_mode(oracle_mod.LSB); refs[c].set_mixer(f0[c]); refs[c].set_filter(-3000, -300)
+        rx.set_mode(c, P.DM_LSB); rx.set_mixer(c, f0[c]); rx.set_bandpass(c, -3000, -300)
+    sf = rx.superframe
+    xs = np.stack([tones(fs, 3 * sf, [(0.2, f0[c] - 1500.0), (0.1, f0[c] + 2000.0)]) + lcg_noise(3 * sf, 10 + c, 1e-3) for c in range(C)])
+    for call in range(3):
+        if call == 1:
+            refs[1].set_mixer(-201e3); rx.set_mixer(1, -201e3)
+            refs[2].set_filter(-2500, -500); rx.set_bandpass(2, -2500, -500)
+        if call == 2:
+            refs[0].set_mode(oracle_mod.NONE); rx.set_mode(0, P.DM_NONE)
+        a, s = rx.process(xs[:, call * sf:(call + 1) * sf])
+        for c in range(C):
+            outs = [refs[c].process(xs[c, call * sf + f * n: call * sf + (f + 1) * n]) for f in range(sf // n)]
+            r = np.concatenate([o[0] for o in outs])
+            rs = np.array([o[1] for o in outs])
+            if call == 2 and c == 0:
+                # dmNONE: the reference clears m_audioBuf and returns (receiver.cpp:968-971); the bank leaves the
+                # band-passed samples in place and the host discards them -- both produce no audio downstream
+                continue
+            assert rel_rms(a[c], r) <= TOL
+            assert db_err(s[c], rs) <= TOL_DB
+
+
+def test_error_paths(gpu_lib):
+    import pebblesdr_amd as P
+    rx = P.ReceiverBank(2048000, 2, True, False, 0)
+    with pytest.raises(P.PebbleGpuError) as e:
+        rx.set_mixer(5, 1.0)
+    assert e.value.code == -1
+    with pytest.raises(P.PebbleGpuError) as e:
+        rx.set_bandpass(0, 3000, 300)  # lo >= hi: "Filter Parameter error"
+    assert e.value.code == -4
+    with pytest.raises(P.PebbleGpuError) as e:
+        rx.set_mode(0, P.DM_FMN)
+    assert e.value.code == -6
+    buf = P.DeviceBuffer(8 * 1000)
+    with pytest.raises(P.PebbleGpuError) as e:
+        rx.process_device(buf.ptr, 1000)  # not a whole super-frame
+    assert e.value.code == -5
+    with pytest.raises(P.PebbleGpuError):
+        P.ReceiverBank(2048000, 1, True, False, 1 << 16)  # 65536 bins clamps to 65535: not a power of two (fft.cpp:76-77)
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes (no oracle: it would take minutes)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties_config2(gpu_lib):
+    """Properties that need no oracle, on a 2 Mi-sample call of the bench workload: (a) call-splitting invariance:
+    one 16-super-frame call equals sixteen 1-super-frame calls, bit for bit in the spectrum and to ~1e-6 in audio
+    (the long call runs the chunk-parallel warm-up scans, the short ones the exact carried state);
+    (b) a bin-centred -10 dBFS tone reads -10.00 dB at the right bin in every frame; (c) the audio of an unmodulated
+    carrier is ~0 after the start-up transient."""
+    import pebblesdr_amd as P
+    fs, n = 20_000_000, 2048
+    k = 16
+    a_rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=k)
+    b_rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=1)
+    sf = a_rx.superframe
+    N = k * sf
+    fbin = fs * 205 / 2048  # bin-centred for the 2048-sample window
+    t = np.arange(N) / fs
+    x = (10 ** (-10 / 20) * np.exp(2j * np.pi * fbin * t)).astype(np.complex64)
+    for rx in (a_rx, b_rx):
+        rx.set_mixer(0, fbin)
+    A, SA = a_rx.process(x)
+    parts = [b_rx.process(x[i * sf:(i + 1) * sf]) for i in range(k)]
+    B = np.concatenate([p[0] for p in parts], axis=1)
+    SB = np.concatenate([p[1] for p in parts], axis=1)
+    assert np.array_equal(SA, SB)
+    assert np.abs(A - B).max() <= 1e-6
+    peaks = SA[0][1:].max(axis=1)
+    assert np.abs(peaks + 10.0).max() < 2e-3
+    assert np.all(np.argmax(SA[0][1:], axis=1) == 4096 + 4 * 205)
+    # unmodulated carrier at DC after mixing: discriminator output 0 (after the start-up transient)
+    assert np.abs(A[0][4096:]).max() < 1e-4
