@@ -81,7 +81,8 @@ def test_decimator_short_frame_is_an_error_not_a_degraded_filter(gpu_lib):
 def test_fastfir_step(gpu_lib, oracle_mod, fft, taps, lo, hi):
     import pebblesdr_amd as P
     n = 2048
-    x = tones(64000, 8 * n, [(0.4873, 1000.0), (0.3, -12000.0), (0.2, 1250.0)]) + lcg_noise(8 * n, 4, 1e-3)
+    # one tone inside every pass-band under test plus a strong out-of-band one
+    x = tones(64000, 8 * n, [(0.4873, 1000.0), (0.3, -12000.0), (0.2, 1250.0), (0.25, -1700.0)]) + lcg_noise(8 * n, 4, 1e-3)
     ref = oracle_mod.FastFIR(fft, taps)
     ref.setup(lo, hi, 0, 64000)
     f = P.FastFIR(fft, taps)
