@@ -45,6 +45,19 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
 
+// Wave-private LDS hand-off: lanes of one wave run in lockstep and its LDS operations retire in order, so
+// this only has to stop the compiler from moving LDS accesses across the point (no s_barrier is emitted).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// compiler-only helpers: hide a value from loop-invariant code motion / pin the instruction schedule at a point
+__device__ __forceinline__ void opaque(int &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // e^{j 2 pi c}, c in cycles (fp64), reduced to [-0.5, 0.5) before the fp32 sincos
 __device__ __forceinline__ float2 cis_cycles(double c)
 {

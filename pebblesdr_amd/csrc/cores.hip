@@ -441,9 +441,20 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     for (uint32_t i = 0; i < nf; i++) wf[i] = (float)w[i];
     PG_HIP(hipMalloc((void **)&d_window, sizeof(float) * nf));
     PG_HIP(hipMemcpy(d_window, wf.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    // btab[q][m] = exp(-2*pi*i*(64*m*q)/bins): the wave-uniform factor of the pruned-FFT pre-twiddle W_bins^{n q},
+    // n = lane + 64 m (the per-lane factor W_bins^{lane q} is computed in the kernel)
+    const uint32_t zp = bins / nf;
+    std::vector<float2> bt((size_t)zp * 32);
+    for (uint32_t q = 0; q < zp; q++)
+        for (uint32_t m = 0; m < 32; m++) {
+            const uint64_t k = ((uint64_t)64 * m * q) % bins;
+            const double a = -design::kTwoPi * (double)k / (double)bins;
+            bt[(size_t)q * 32 + m] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    PG_HIP(hipMalloc((void **)&d_btab, sizeof(float2) * bt.size()));
+    PG_HIP(hipMemcpy(d_btab, bt.data(), sizeof(float2) * bt.size(), hipMemcpyHostToDevice));
     scale = (float)(1.0 / (cg * (double)nf));  // /coherentGain then /maxBinPower, fft.cpp:347,355
     if (int rc = make_twiddles(2048, &d_tw_nf)) return rc;
-    if (int rc = make_twiddles((int)bins, &d_tw_bins)) return rc;
     for (int i = 0; i < 2; i++) {
         PG_HIP(hipMalloc((void **)&d_prev[i], sizeof(float) * (size_t)bins * S));
         PG_HIP(hipMemset(d_prev[i], 0, sizeof(float) * (size_t)bins * S));  // the reference leaves these uninitialised (fft.cpp:107-115)
@@ -452,26 +463,27 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_prev[0], d_prev[1], d_tw_nf, d_tw_bins};
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf};
     for (void *q : p) if (q) (void)hipFree(q);
-    d_window = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = d_tw_bins = nullptr;
+    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr;
 }
 int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out)
 {
     SpectrumParams sp;
     sp.in_pitch = in_pitch;
     sp.n_frames = F;
-    long long G = (F * (long long)S) / 2048;  // aim for ~2048 workgroups; each recomputes one extra frame
+    const int groups = 4 / (int)(bins / nf);  // wave groups (frames in flight) per workgroup
+    long long G = (F * (long long)S) / (1024 * groups);  // aim for ~1024 workgroups; each group recomputes one extra frame
     G = G < 1 ? 1 : (G > 16 ? 16 : G);
     sp.frames_per_group = (int)G;
     sp.scale = scale;
     sp.out_pitch = F * (long long)bins;
-    const dim3 grid(cdiv(F, G), S), block(256);
+    const dim3 grid(cdiv(F, G * groups), S), block(256);
     const float *pin = d_prev[parity];
     float *pout = d_prev[parity ^ 1];
-    if (bins == 2048) launch(k_spectrum<1>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_tw_nf, (const float2 *)d_tw_bins, pin, pout, sp);
-    else if (bins == 4096) launch(k_spectrum<2>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_tw_nf, (const float2 *)d_tw_bins, pin, pout, sp);
-    else launch(k_spectrum<4>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_tw_nf, (const float2 *)d_tw_bins, pin, pout, sp);
+    if (bins == 2048) launch(k_spectrum<1>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
+    else if (bins == 4096) launch(k_spectrum<2>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
+    else launch(k_spectrum<4>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
     parity ^= 1;
     PG_HIP(hipGetLastError());
     return 0;

@@ -1,9 +1,12 @@
-// fft_lds.h -- workgroup FFT for N in {2048, 4096, 8192}: 256 work-items, N/256 points per
-// work-item held in registers, Stockham autosort passes (radix 8, with one leading radix-4 or
-// radix-2 pass) exchanged through LDS.  fp32, twiddles from an fp64-rounded table W_N[m] =
-// exp(-2*pi*i*m/N) resident in L1/L2.
+// fft_lds.h -- cooperative FFT for N in {2048, 4096, 8192}: T work-items (a 256-item workgroup, or ONE
+// 64-lane wave for N = 2048), N/T points per work-item held in registers, Stockham autosort passes
+// (radix 8, with one leading radix-4 or radix-2 pass) exchanged through LDS.  fp32, twiddles from an
+// fp64-rounded table W_N[m] = exp(-2*pi*i*m/N) resident in L1/L2.
 //
-// Register layout ("strided"): x[m] holds element  tid + 256*m.  The first pass reads its butterfly
+// With T = 64 the exchange is wave-private: a wave's LDS operations retire in issue order, so the passes
+// need no s_barrier at all -- four waves of a workgroup run four independent transforms.
+//
+// Register layout ("strided"): x[m] holds element  tid + T*m.  The first pass reads its butterfly
 // inputs from exactly those slots and the last pass leaves its outputs in exactly those slots, so a
 // forward transform, a pointwise product and an inverse transform chain with no extra exchange
 // (the overlap-save band-pass does that), and global loads/stores of x[] are coalesced.
@@ -69,26 +72,39 @@ template <int R, int DIR> __device__ __forceinline__ void bfly(float2 *u)
     else bfly8<DIR>(u);
 }
 
-// One Stockham pass.  P = product of the radices of the passes before this one.
-template <int N, int R, int P, int DIR, bool FIRST, bool LAST>
-__device__ __forceinline__ void fft_pass(float2 (&x)[N / 256], float2 *lds, const float2 *__restrict__ tw, int tid)
+template <int T> __device__ __forceinline__ void fft_sync()
 {
-    constexpr int E = N / 256, Q = E / R;
+    if (T == 64) wave_sync();
+    else __syncthreads();
+}
+
+// One Stockham pass.  P = product of the radices of the passes before this one.
+template <int N, int T, int R, int P, int DIR, bool FIRST, bool LAST>
+__device__ __forceinline__ void fft_pass(float2 (&x)[N / T], float2 *lds, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int E = N / T, Q = E / R;
     static_assert(E % R == 0 && Q >= 1, "points per work-item must be a multiple of the radix");
     if (!FIRST) {
+        {
+            // lpad(tid + T*m) == lpad(tid) + lpad(T*m) because T is a multiple of 32: one base, immediate offsets
+            const float2 *rp = lds + lpad(tid);
 #pragma unroll
-        for (int m = 0; m < E; m++) x[m] = lds[lpad(tid + 256 * m)];
-        __syncthreads();  // all gathers done before any work-item scatters again
+            for (int m = 0; m < E; m++) x[m] = rp[lpad(T * m)];
+        }
+        fft_sync<T>();  // all gathers done before any work-item scatters again
     }
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        const int b = tid + 256 * q;
+        const int b = tid + T * q;
         float2 u[R];
 #pragma unroll
         for (int r = 0; r < R; r++) u[r] = x[q + r * Q];
         const int k = b & (P - 1);
         if (P > 1) {
-            const int i1 = k * (N / (P * R));
+            int i1 = k * (N / (P * R));
+            // Twiddles are loop-invariant in a kernel that transforms frame after frame; hoisting all of them costs
+            // up to 84 VGPRs (spills at 2 waves/SIMD).  Keep them as L1-resident loads next to their use instead.
+            if (T == 64) opaque(i1);
             const float2 w1 = twid<DIR>(tw[i1]);
             u[1] = cmul(u[1], w1);
             if (R >= 4) {
@@ -107,39 +123,43 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[N / 256], float2 *lds, cons
         }
         bfly<R, DIR>(u);
         if (LAST) {
-            // P == N/R here, so k == b and output r lands on element b + r*N/R = tid + 256*(q + r*Q)
+            // P == N/R here, so k == b and output r lands on element b + r*N/R = tid + T*(q + r*Q)
 #pragma unroll
             for (int r = 0; r < R; r++) x[q + r * Q] = u[r];
         } else {
+            // lpad(j + r*P) == lpad(j) + lpad(r*P): (j mod 32) + (r*P mod 32) never carries for power-of-two P
+            // (j = P*R*c + k with k < P), so the R scatters share one base register and use immediate offsets
             const int j = (b - k) * R + k;
+            float2 *wp = lds + lpad(j);
 #pragma unroll
-            for (int r = 0; r < R; r++) lds[lpad(j + r * P)] = u[r];
+            for (int r = 0; r < R; r++) wp[lpad(r * P)] = u[r];
         }
+        if (T == 64) sched_fence();  // one butterfly at a time: interleaving all Q of them multiplies the live set
     }
-    if (!LAST) __syncthreads();
+    if (!LAST) fft_sync<T>();
 }
 
-// Whole transform, strided registers in and out.  lds: FftLds<N>::kSlots float2.  All 256 work-items call.
-template <int N, int DIR>
-__device__ __forceinline__ void fft_regs(float2 (&x)[N / 256], float2 *lds, const float2 *__restrict__ tw, int tid)
+// Whole transform, strided registers in and out.  lds: FftLds<N>::kSlots float2 (private to the T work-items).
+template <int N, int DIR, int T = 256>
+__device__ __forceinline__ void fft_regs(float2 (&x)[N / T], float2 *lds, const float2 *__restrict__ tw, int tid)
 {
-    static_assert(N == 2048 || N == 4096 || N == 8192, "supported workgroup FFT sizes");
+    static_assert((T == 256 && (N == 2048 || N == 4096 || N == 8192)) || (T == 64 && N == 2048), "supported sizes");
     if (N == 2048) {
-        fft_pass<N, 4, 1, DIR, true, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 4, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 32, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 256, DIR, false, true>(x, lds, tw, tid);
+        fft_pass<N, T, 4, 1, DIR, true, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 4, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 32, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 256, DIR, false, true>(x, lds, tw, tid);
     } else if (N == 4096) {
-        fft_pass<N, 8, 1, DIR, true, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 8, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 64, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 512, DIR, false, true>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 1, DIR, true, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 8, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 64, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 512, DIR, false, true>(x, lds, tw, tid);
     } else {
-        fft_pass<N, 2, 1, DIR, true, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 2, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 16, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 128, DIR, false, false>(x, lds, tw, tid);
-        fft_pass<N, 8, 1024, DIR, false, true>(x, lds, tw, tid);
+        fft_pass<N, T, 2, 1, DIR, true, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 2, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 16, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 128, DIR, false, false>(x, lds, tw, tid);
+        fft_pass<N, T, 8, 1024, DIR, false, true>(x, lds, tw, tid);
     }
 }
 

@@ -6,100 +6,149 @@
 // (pebblelib/fft.cpp:129-157, 207-213, 324-399; fftaccelerate.cpp:106-119).
 //
 // Zero-padding is pruned instead of transformed: with x[n] = 0 for n >= NF,
-//   X[ZP*j + q] = FFT_NF( x[n] * W_bins^{n*q} )[j],  q = 0..ZP-1
-// i.e. ZP independent NF-point transforms of the twiddled frame -- log2(ZP) butterfly passes over
-// zeros are never executed, and each work-item ends up holding ZP adjacent bins (one vector store).
+//   X[ZP*j + q] = FFT_NF( x[n] * w[n] * W_bins^{n*q} )[j],  q = 0..ZP-1
+// i.e. ZP independent NF-point transforms of the windowed frame times a per-q twiddle -- log2(ZP) butterfly
+// passes over zeros are never executed.
 //
-// A workgroup walks G consecutive frames of one stream so the previous frame's amplitudes stay in
-// registers; it recomputes one extra frame (the one before its first) for the average.
+// Mapping: one WAVE per (frame, q); the ZP waves of a frame form a group, a 256-item workgroup holds 4/ZP groups.
+//   * the group's waves load the NEXT frame once, cooperatively (each wave a 1/ZP slice, coalesced, issued before
+//     the current frame's transform so HBM latency hides under it), apply the window and park it in LDS;
+//   * each wave gathers the whole windowed frame from LDS in the FFT's strided register layout and applies its
+//     twiddle as W^{lane*q} (one per-lane constant) times W^{64*m*q} (wave-uniform, scalar registers);
+//   * the 2048-point transform runs inside the wave (32 points per lane, wave-private LDS exchange, no
+//     s_barrier -- fft_lds.h);
+//   * the wave keeps its q-slice of the previous frame's amplitudes in registers, and parks its 2048 dB values
+//     in its own LDS region; after a workgroup barrier the group interleaves the q-slices so each lane stores
+//     ZP adjacent bins as one 16-byte vector, fully coalesced.
+// A group walks G consecutive frames and recomputes one extra frame (the one before its first) to seed the
+// average.  Three workgroup barriers per frame; 72 KiB LDS -> two workgroups per CU.
 //
-// Bound: HBM first (8*NF B in, 4*bins B out per frame), fp32 ALU/LDS close behind at ZP = 4
-// (about 0.5 Mflop per frame).  Algorithmic bytes per frame: 8*NF + 4*bins.
+// Bound: HBM (8*NF B in + 4*bins B out per frame) with LDS / fp32 ALU close behind at ZP = 4 (~0.5 Mflop/frame).
+// Algorithmic bytes per frame: 8*NF + 4*bins.
 #pragma once
 #include "fft_lds.h"
 #include "params.h"
 
 namespace pg {
 
-
 template <int ZP>
-__global__ __launch_bounds__(256) void k_spectrum(const float2 *__restrict__ in, float *__restrict__ out,
-                                                   const float *__restrict__ window, const float2 *__restrict__ tw_nf,
-                                                   const float2 *__restrict__ tw_bins,
-                                                   const float *__restrict__ prev_in, float *__restrict__ prev_out,
-                                                   SpectrumParams sp)
+__global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ in, float *__restrict__ out,
+                                                      const float *__restrict__ window, const float2 *__restrict__ btab,
+                                                      const float2 *__restrict__ tw_nf, const float *__restrict__ prev_in,
+                                                      float *__restrict__ prev_out, SpectrumParams sp)
 {
-    constexpr int NF = 2048, E = NF / 256, BINS = NF * ZP;
-    __shared__ float2 lds[FftLds<NF>::kSlots];
-    const int tid = threadIdx.x, s = blockIdx.y;
-    const long long f0 = (long long)blockIdx.x * sp.frames_per_group;
-    long long f1 = f0 + sp.frames_per_group;
-    if (f1 > sp.n_frames) f1 = sp.n_frames;
+    constexpr int NF = 2048, E = NF / 64, BINS = NF * ZP, GROUPS = 4 / ZP, TG = 64 * ZP;
+    constexpr int SL = NF / ZP, EL = E / ZP;  // slice of the frame one wave loads, points per lane of it
+    // a wave's LDS region: FFT exchange image [0, kSlots), aliased by its dB slice (floats, first 8 KiB) and, behind
+    // that, by the windowed slice of the next frame it parks for the group ([XOFF, XOFF+SL))
+    constexpr int XOFF = NF / 2;
+    constexpr int REGION = (XOFF + SL > FftLds<NF>::kSlots) ? XOFF + SL : FftLds<NF>::kSlots;
+    __shared__ float2 lds[4][REGION];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave / ZP, q = wave % ZP, s = blockIdx.y;
+    const int G = sp.frames_per_group;
+    const long long f0 = ((long long)blockIdx.x * GROUPS + g) * G;
     const float2 *x = in + (long long)s * sp.in_pitch;
     float *y = out + (long long)s * sp.out_pitch;
+    float2 *my = lds[wave];
+    float *stage = reinterpret_cast<float *>(my);  // this wave's dB slice, [j] for bins ZP*j + q
 
-    float w[E];
+    float win[EL];  // window values of the slice this wave loads: constant over frames
 #pragma unroll
-    for (int m = 0; m < E; m++) w[m] = window[tid + 256 * m];
+    for (int i = 0; i < EL; i++) win[i] = window[q * SL + lane + 64 * i];
+    const float2 tw_lane = cis_cycles(-(double)(lane * q) / (double)BINS);  // W_bins^{lane q}
+    const float2 *bq = btab + q * E;                                         // W_bins^{64 m q}, m < E (wave-uniform)
 
-    float pa[ZP][E];  // previous frame's linear amplitudes, element (q, m) <-> bin ZP*(tid+256m)+q
-    for (long long f = f0 - 1; f < f1; f++) {
-        float amp[ZP][E];
-        if (f < 0) {
-            // frame before the call: amplitudes saved by the previous call (zeros on the first)
+    float pa[E];  // previous frame's linear amplitudes of bins ZP*(lane+64m)+q
+    float2 xn[EL];
+    // prologue: park the first frame this group transforms (f0 - 1, or frame 0 at the call boundary)
+    {
+        const long long ff = f0 > 0 ? f0 - 1 : 0;
+        if (ff < sp.n_frames) {
 #pragma unroll
-            for (int q = 0; q < ZP; q++)
+            for (int i = 0; i < EL; i++) xn[i] = x[ff * NF + q * SL + lane + 64 * i];
 #pragma unroll
-                for (int m = 0; m < E; m++) pa[q][m] = prev_in[(long long)s * BINS + ZP * (tid + 256 * m) + q];
-            continue;
+            for (int i = 0; i < EL; i++) my[XOFF + lane + 64 * i] = cscale(xn[i], win[i]);
         }
-        float2 xin[E];
+    }
+    __syncthreads();
+
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        const bool live = f < sp.n_frames;  // wave-uniform
+        const bool xform = live && f >= 0;
+        // Everything below is addressed from `ln`, an opaque copy of the lane id: without it the compiler hoists
+        // ~200 loop-invariant LDS/global addresses and twiddles out of the frame loop and then spills them.
+        int ln = lane;
+        opaque(ln);
+        // the frame the next iteration transforms: issue its loads now so HBM latency hides under this transform
+        // (when f0 == 0 iteration -1 transforms nothing and frame 0 is already parked)
+        const bool fetch = it + 1 < G && f + 1 < sp.n_frames && f >= 0;
+        if (fetch) {
+            const float2 *xp = x + (f + 1) * NF + q * SL + ln;
 #pragma unroll
-        for (int m = 0; m < E; m++) xin[m] = cscale(x[f * NF + tid + 256 * m], w[m]);
-#pragma unroll
-        for (int q = 0; q < ZP; q++) {
-            float2 v[E];
+            for (int i = 0; i < EL; i++) xn[i] = xp[64 * i];
+        }
+        float2 v[E];
+        if (xform) {
+            // sample n = ln + 64 m is parked in the region of wave n / SL = (64 m) / SL of this group
+            const float2 *gp = &lds[g * ZP][XOFF + ln];
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                if (q == 0) v[m] = xin[m];
-                else v[m] = cmul(xin[m], tw_bins[(tid + 256 * m) * q]);  // W_bins^{n q}, n*q < bins
+                const float2 xv = gp[((64 * m) / SL) * REGION + (64 * m) % SL];
+                v[m] = ZP == 1 ? xv : cmul(cmul(xv, tw_lane), bq[m]);
             }
-            fft_regs<NF, +1>(v, lds, tw_nf, tid);
-#pragma unroll
-            for (int m = 0; m < E; m++) amp[q][m] = sqrtf(v[m].x * v[m].x + v[m].y * v[m].y) * sp.scale;
         }
-        if (f >= f0) {
+        __syncthreads();  // A: every wave holds the frame in registers; regions may be overwritten
+        if (live && f < 0) {
+            // the frame before this call: amplitudes saved by the previous call (zeros on the first)
+            const float *pp = prev_in + (long long)s * BINS + ZP * ln + q;
+#pragma unroll
+            for (int m = 0; m < E; m++) pa[m] = pp[ZP * 64 * m];
+        } else if (xform) {
+            fft_regs<NF, +1, 64>(v, my, tw_nf, ln);
+            float *st = stage + ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const float amp = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y) * sp.scale;
+                const float a = 0.5f * (amp + pa[m]);  // fft.cpp:379-381
+                // 20*log10(a) = 6.0206*log2(a); a == 0 gives -inf which the clip turns into -120 (db.h:24-26,44-48)
+                const float d = 6.02059991327962f * __builtin_amdgcn_logf(a);
+                st[64 * m] = fminf(fmaxf(d, -120.f), 0.f);  // for it == -1 nobody reads this slice
+                pa[m] = amp;
+            }
+            if (f == sp.n_frames - 1) {
+                float *pp = prev_out + (long long)s * BINS + ZP * ln + q;
+#pragma unroll
+                for (int m = 0; m < E; m++) pp[ZP * 64 * m] = pa[m];
+            }
+        }
+        __syncthreads();  // B: dB slices parked, exchanges finished
+        if (fetch) {
+            float2 *xs = my + XOFF + ln;
+#pragma unroll
+            for (int i = 0; i < EL; i++) xs[64 * i] = cscale(xn[i], win[i]);
+        }
+        if (it >= 0 && live) {
+            // the ZP waves of this frame interleave their slices: lane tg owns sub-bins j = tg + TG*i
+            const int tg = ln + 64 * q;
+            const float *sp0 = reinterpret_cast<const float *>(lds[g * ZP]) + tg;
             float *yf = y + f * (long long)BINS;
 #pragma unroll
-            for (int m = 0; m < E; m++) {
+            for (int i = 0; i < NF / TG; i++) {
+                const int j = tg + TG * i;
                 float db[ZP];
 #pragma unroll
-                for (int q = 0; q < ZP; q++) {
-                    const float a = 0.5f * (amp[q][m] + pa[q][m]);   // fft.cpp:379-381
-                    float d = a == 0.f ? -120.f : 20.f * log10f(a);   // db.h:44-48
-                    d = fminf(fmaxf(d, -120.f), 0.f);                 // db.h:24-26
-                    db[q] = d;
-                }
-                // bin k = ZP*j+q unfolds to (k + BINS/2) mod BINS (fft.cpp:207-213); ZP adjacent bins stay adjacent
-                const int k = ZP * (tid + 256 * m);
-                const int u = (k + BINS / 2) & (BINS - 1);
+                for (int qq = 0; qq < ZP; qq++) db[qq] = sp0[qq * (REGION * 2) + TG * i];
+                // bin k = ZP*j + qq unfolds to (k + BINS/2) mod BINS (fft.cpp:207-213); the ZP bins stay adjacent
+                const int u = (ZP * j + BINS / 2) & (BINS - 1);
                 if (ZP == 4) *reinterpret_cast<float4 *>(yf + u) = make_float4(db[0], db[1], db[2], db[3]);
                 else if (ZP == 2) *reinterpret_cast<float2 *>(yf + u) = make_float2(db[0], db[1]);
-                else
-#pragma unroll
-                    for (int q = 0; q < ZP; q++) yf[u + q] = db[q];
+                else yf[u] = db[0];
             }
         }
-#pragma unroll
-        for (int q = 0; q < ZP; q++)
-#pragma unroll
-            for (int m = 0; m < E; m++) pa[q][m] = amp[q][m];
-        if (f == sp.n_frames - 1) {
-#pragma unroll
-            for (int q = 0; q < ZP; q++)
-#pragma unroll
-                for (int m = 0; m < E; m++) prev_out[(long long)s * BINS + ZP * (tid + 256 * m) + q] = amp[q][m];
-        }
+        __syncthreads();  // C: next frame parked, dB slices consumed
     }
 }
 

@@ -124,8 +124,9 @@ struct WfmCore {
 // ---- FFT::fftSpectrum ----
 struct SpectrumCore {
     uint32_t S = 0, nf = 2048, bins = 0;
-    float *d_window = nullptr, *d_prev[2] = {nullptr, nullptr};
-    float2 *d_tw_nf = nullptr, *d_tw_bins = nullptr;
+    float *d_prev[2] = {nullptr, nullptr};
+    float *d_window = nullptr;
+    float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
     float scale = 0;
     int parity = 0;
     int init(uint32_t streams, uint32_t frame, uint32_t fft_size);

@@ -415,14 +415,14 @@ def test_error_paths(gpu_lib):
 # size-independent properties at BASELINE sizes (no oracle: it would take minutes)
 # ------------------------------------------------------------------------------------------------
 def test_full_size_properties_config2(gpu_lib):
-    """Properties that need no oracle, on a 2 Mi-sample call of the bench workload: (a) call-splitting invariance:
-    one 16-super-frame call equals sixteen 1-super-frame calls, bit for bit in the spectrum and to ~1e-6 in audio
+    """Properties that need no oracle, on an 8 Mi-sample call of the bench workload: (a) call-splitting invariance:
+    one 64-super-frame call (4 frames per wave group) equals sixty-four 1-super-frame calls, bit for bit in the spectrum and to ~1e-6 in audio
     (the long call runs the chunk-parallel warm-up scans, the short ones the exact carried state);
     (b) a bin-centred -10 dBFS tone reads -10.00 dB at the right bin in every frame; (c) the audio of an unmodulated
     carrier is ~0 after the start-up transient."""
     import pebblesdr_amd as P
     fs, n = 20_000_000, 2048
-    k = 16
+    k = 64
     a_rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=k)
     b_rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=1)
     sf = a_rx.superframe

@@ -186,6 +186,14 @@ template <class T> static inline T __shfl_xor(T v, int m, int width = 64)
     return hipemu::shfl_idx(v, lane ^ m);
 }
 
+// wave-level builtins used by common.h's wave_sync()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::yield_as(2); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+
 // device math the kernels use
 static inline void sincospif(float x, float *s, float *c)
 {
