@@ -63,7 +63,7 @@ void fill_scan_section(ScanSection &s, int type, const double *c)
     }
 }
 
-// how many 2048-sample sub-chunks of zero-state warm-up make radius^samples < tol; -1 if more than 2
+// how many kSub-sample sub-chunks of zero-state warm-up make radius^samples < tol; -1 if more than 8
 int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol)
 {
     double r = 0;
@@ -72,7 +72,7 @@ int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol)
     if (r >= 1) return -1;
     const double need = std::log(tol) / std::log(r) * 1.5 + 64;  // margin for the non-normal transient
     const int subs = (int)std::ceil(need / kSub);
-    return subs <= 2 ? (subs < 1 ? 1 : subs) : -1;
+    return subs <= 8 ? (subs < 1 ? 1 : subs) : -1;
 }
 
 int make_twiddles(int n, float2 **d_tw)
@@ -232,12 +232,25 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     PG_HIP(hipGetLastError());
     return 0;
 }
-int DecimCore::save_tails(hipStream_t s)
+void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
     for (size_t k = 0; k < stage.size(); k++)
-        if (stage[k].hist > 0)
-            launch(k_save_tail, dim3(cdiv(stage[k].hist, 256), C), dim3(256), s, stage[k].data(), stage[k].pitch, lens[k], stage[k].hist,
-                   (const int *)nullptr);
+        if (stage[k].hist > 0) jobs.push_back(TailJob{stage[k].data(), stage[k].pitch, lens[k], stage[k].hist, 0});
+}
+
+int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels)
+{
+    if (jobs.empty()) return 0;
+    if (jobs.size() > (size_t)kMaxTailJobs) return fail(PEBBLEGPU_E_INVALID, "too many history buffers");
+    TailJobs tj;
+    memset(&tj, 0, sizeof(tj));
+    tj.count = (int)jobs.size();
+    int maxh = 1;
+    for (size_t i = 0; i < jobs.size(); i++) {
+        tj.job[i] = jobs[i];
+        if (jobs[i].hist > maxh) maxh = jobs[i].hist;
+    }
+    launch(k_save_tails, dim3(cdiv(maxh, 256), channels, (unsigned)jobs.size()), dim3(256), s, tj);
     PG_HIP(hipGetLastError());
     return 0;
 }
@@ -400,7 +413,7 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
     if (n > a.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
     if (n < b.hist) return fail(PEBBLEGPU_E_SIZE, "WFM demod needs at least %d samples per call", b.hist);
     const long long nsub = (n + kSub - 1) / kSub;
-    const int spb = 4;  // output sub-chunks per workgroup in chunk-parallel mode
+    const int spb = 2;  // output sub-chunks per workgroup in chunk-parallel mode (each also re-runs warm_* before them)
     if (lp_on) {
         const unsigned gx = warm_lp < 0 ? 1u : cdiv(nsub, spb);
         launch(k_iir_scan<0, 1>, dim3(gx, C), dim3(64), s, in, in_pitch, a.data(), a.pitch, n, lp, (const double *)d_lp_state[parity],
@@ -416,11 +429,15 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         launch(k_iir_scan<1, 2>, dim3(gx, C), dim3(64), s, (const float2 *)c.data(), c.pitch, out, out_pitch, n, dn,
                (const double *)d_dn_state[parity], d_dn_state[parity ^ 1], warm_dn < 0 ? (int)nsub : spb, warm_dn, (const int *)nullptr);
     }
-    launch(k_save_tail, dim3(1, C), dim3(256), s, a.data(), a.pitch, n, a.hist, (const int *)nullptr);
-    launch(k_save_tail, dim3(1, C), dim3(256), s, b.data(), b.pitch, n, b.hist, (const int *)nullptr);
     parity ^= 1;
+    last_n = n;
     PG_HIP(hipGetLastError());
     return 0;
+}
+void WfmCore::tail_jobs(std::vector<TailJob> &jobs) const
+{
+    jobs.push_back(TailJob{a.data(), a.pitch, last_n, a.hist, 0});
+    jobs.push_back(TailJob{b.data(), b.pitch, last_n, b.hist, 0});
 }
 
 // ------------------------------------------------------------------------------------------------

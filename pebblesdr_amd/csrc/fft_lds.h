@@ -93,6 +93,19 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[N / T], float2 *lds, const 
         }
         fft_sync<T>();  // all gathers done before any work-item scatters again
     }
+    // Twiddle base powers w1, w2, w4 come from the table; when P <= T the index k = b & (P-1) is the same for all Q
+    // butterflies of this work-item, so they are fetched once per pass.
+    float2 w1 = make_float2(1.f, 0.f), w2 = w1, w4 = w1;
+    auto fetch_tw = [&](int k) {
+        int i1 = k * (N / (P * R));
+        // Twiddles are loop-invariant in a kernel that transforms frame after frame; hoisting all of them costs
+        // dozens of VGPRs (spills at 2 waves/SIMD).  Keep them as table loads next to their use instead.
+        if (T == 64) opaque(i1);
+        w1 = twid<DIR>(tw[i1]);
+        if (R >= 4) w2 = twid<DIR>(tw[2 * i1]);
+        if (R == 8) w4 = twid<DIR>(tw[4 * i1]);
+    };
+    if (P > 1 && P <= T) fetch_tw(tid & (P - 1));
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int b = tid + T * q;
@@ -101,19 +114,13 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[N / T], float2 *lds, const 
         for (int r = 0; r < R; r++) u[r] = x[q + r * Q];
         const int k = b & (P - 1);
         if (P > 1) {
-            int i1 = k * (N / (P * R));
-            // Twiddles are loop-invariant in a kernel that transforms frame after frame; hoisting all of them costs
-            // up to 84 VGPRs (spills at 2 waves/SIMD).  Keep them as L1-resident loads next to their use instead.
-            if (T == 64) opaque(i1);
-            const float2 w1 = twid<DIR>(tw[i1]);
+            if (P > T) fetch_tw(k);
             u[1] = cmul(u[1], w1);
             if (R >= 4) {
-                const float2 w2 = twid<DIR>(tw[2 * i1]);
                 const float2 w3 = cmul(w1, w2);
                 u[2] = cmul(u[2], w2);
                 u[3] = cmul(u[3], w3);
                 if (R == 8) {
-                    const float2 w4 = twid<DIR>(tw[4 * i1]);
                     u[4] = cmul(u[4], w4);
                     u[5] = cmul(u[5], cmul(w4, w1));
                     u[6] = cmul(u[6], cmul(w4, w2));

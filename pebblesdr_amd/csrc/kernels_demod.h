@@ -2,9 +2,9 @@
 //
 // The reference's demodulators are serial per sample: AM DC-block (demod_am.cpp:52-57), CIir
 // biquads (pebblelib/iir.cpp:176-207) and the one-pole de-emphasis (demod_wfm.cpp:476-485).  All are
-// LINEAR recurrences, so a wave evaluates 2048 samples at once: lane l owns 32 consecutive samples,
+// LINEAR recurrences, so a wave evaluates kSub = 512 samples at once: lane l owns kSeg = 8 consecutive samples,
 // runs them from a zero state, the 64 end states are combined with a Hillis-Steele scan using the
-// precomputed transition powers M^(32*2^k), and each lane re-runs its samples from its true entry state.
+// precomputed transition powers M^(kSeg*2^k), and each lane re-runs its samples from its true entry state.
 // Recurrence arithmetic is fp64 (the DC-block pole 0.9999 needs it); samples are stored fp32.
 //
 // Across workgroups a long single-channel stream is cut into chunks; a chunk that does not start at
@@ -16,7 +16,7 @@
 namespace pg {
 
 
-__device__ __forceinline__ int spad(int i) { return i + (i >> 5); }  // lane stride 32 -> 33: conflict-free
+__device__ __forceinline__ int spad(int i) { return i + i / kSeg; }  // lane stride kSeg -> kSeg+1 dwords: conflict-free
 
 __device__ __forceinline__ double sec_step(const ScanSection &S, double &s0, double &s1, double u)
 {
@@ -45,6 +45,7 @@ __device__ __forceinline__ void scan_sub(const ScanSection &S, float *buf, int n
     int cnt = nv - base;
     cnt = cnt < 0 ? 0 : (cnt > kSeg ? kSeg : cnt);
     double s0 = lane == 0 ? c0 : 0.0, s1 = lane == 0 ? c1 : 0.0;
+#pragma unroll
     for (int i = 0; i < kSeg; i++) {
         const double u = i < cnt ? (double)buf[spad(base + i)] : 0.0;
         (void)sec_step(S, s0, s1, u);
@@ -59,11 +60,14 @@ __device__ __forceinline__ void scan_sub(const ScanSection &S, float *buf, int n
     }
     double e0 = __shfl_up(s0, 1u), e1 = __shfl_up(s1, 1u);
     if (lane == 0) { e0 = c0; e1 = c1; }
-    for (int i = 0; i < cnt; i++) {
-        const int a = spad(base + i);
-        buf[a] = (float)sec_step(S, e0, e1, (double)buf[a]);
+#pragma unroll
+    for (int i = 0; i < kSeg; i++) {
+        if (i < cnt) {
+            const int a = spad(base + i);
+            buf[a] = (float)sec_step(S, e0, e1, (double)buf[a]);
+        }
     }
-    const int lf = (nv - 1) >> 5;
+    const int lf = (nv - 1) / kSeg;
     c0 = __shfl(e0, lf);
     c1 = __shfl(e1, lf);
 }
@@ -79,8 +83,8 @@ static __global__ __launch_bounds__(64) void k_iir_scan(const float2 *__restrict
                                                   double *__restrict__ state_out, int sub_per_block, int warm_sub,
                                                   const int *__restrict__ chan_list)
 {
-    __shared__ float re[kSub + kSub / 32 + 1];
-    __shared__ float im[kSub + kSub / 32 + 1];
+    __shared__ float re[kSub + kSub / kSeg + 1];
+    __shared__ float im[kSub + kSub / kSeg + 1];
     const int lane = threadIdx.x;
     const int c = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
     const long long nsub = (n + kSub - 1) / kSub;

@@ -184,4 +184,14 @@ static __global__ __launch_bounds__(256) void k_save_tail(float2 *__restrict__ d
     b[-hist + j] = b[n - hist + j];
 }
 
+// All history tails of a call in one launch.  grid (ceil(max hist/256), C, jobs).
+static __global__ __launch_bounds__(256) void k_save_tails(TailJobs jobs)
+{
+    const TailJob &t = jobs.job[blockIdx.z];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= t.hist) return;
+    float2 *b = t.data + (long long)blockIdx.y * t.pitch;
+    b[-t.hist + j] = b[t.n - t.hist + j];
+}
+
 }  // namespace pg

@@ -21,7 +21,8 @@
 //     in its own LDS region; after a workgroup barrier the group interleaves the q-slices so each lane stores
 //     ZP adjacent bins as one 16-byte vector, fully coalesced.
 // A group walks G consecutive frames and recomputes one extra frame (the one before its first) to seed the
-// average.  Three workgroup barriers per frame; 72 KiB LDS -> two workgroups per CU.
+// average.  Three workgroup barriers per frame; 72 KiB of exchange regions + 8 KiB twiddle table = 80 KiB LDS, i.e.
+// exactly two workgroups per CU.
 //
 // Bound: HBM (8*NF B in + 4*bins B out per frame) with LDS / fp32 ALU close behind at ZP = 4 (~0.5 Mflop/frame).
 // Algorithmic bytes per frame: 8*NF + 4*bins.
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
     constexpr int XOFF = NF / 2;
     constexpr int REGION = (XOFF + SL > FftLds<NF>::kSlots) ? XOFF + SL : FftLds<NF>::kSlots;
     __shared__ float2 lds[4][REGION];
+    __shared__ float2 tw_lds[NF / 2];  // W_2048^m, m < 1024: every twiddle index the passes use stays below N/2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave / ZP, q = wave % ZP, s = blockIdx.y;
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
     float *y = out + (long long)s * sp.out_pitch;
     float2 *my = lds[wave];
     float *stage = reinterpret_cast<float *>(my);  // this wave's dB slice, [j] for bins ZP*j + q
+
+    for (int i = threadIdx.x; i < NF / 2; i += 256) tw_lds[i] = tw_nf[i];
 
     float win[EL];  // window values of the slice this wave loads: constant over frames
 #pragma unroll
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 #pragma unroll
             for (int m = 0; m < E; m++) pa[m] = pp[ZP * 64 * m];
         } else if (xform) {
-            fft_regs<NF, +1, 64>(v, my, tw_nf, ln);
+            fft_regs<NF, +1, 64>(v, my, tw_lds, ln);
             float *st = stage + ln;
 #pragma unroll
             for (int m = 0; m < E; m++) {

@@ -23,8 +23,8 @@ struct FirTaps {
     float h[kMaxTaps];
 };
 
-constexpr int kSub = 2048;   // samples one wave scans at a time (64 lanes x 32)
-constexpr int kSeg = 32;
+constexpr int kSeg = 8;               // consecutive samples one lane runs serially
+constexpr int kSub = 64 * kSeg;       // samples one wave scans at a time
 
 enum ScanType { kOnePoleDiff = 0, kOnePoleAvg = 1, kBiquadDf2 = 2 };
 
@@ -35,6 +35,18 @@ struct ScanSection {
     double P[6][4];   // M^(kSeg * 2^k), row-major 2x2, k = 0..5
 };
 template <int NSEC> struct ScanParams { ScanSection sec[NSEC]; };
+
+// history-tail refresh jobs: buf[c][-hist + j] = buf[c][n - hist + j] for every channel c (one launch for all buffers)
+struct TailJob {
+    float2 *data;
+    long long pitch, n;
+    int hist, pad_;
+};
+constexpr int kMaxTailJobs = 12;
+struct TailJobs {
+    int count, pad_;
+    TailJob job[kMaxTailJobs];
+};
 
 struct SpectrumParams {
     long long in_pitch;      // samples between streams

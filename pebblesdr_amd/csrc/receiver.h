@@ -35,6 +35,7 @@ struct HistBuf {
 void fill_scan_section(ScanSection &s, int type, const double *c);
 int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
+int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
 
 // ---- oscillator bank (Mixer state for C channels) ----
 struct OscBank {
@@ -68,7 +69,7 @@ struct DecimCore {
     // runs all stages; n must be a multiple of chain.total and every stage must see >= its consumer's history
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
             hipEvent_t after_first = nullptr);
-    int save_tails(hipStream_t s);
+    void tail_jobs(std::vector<TailJob> &jobs) const;  // after run(): what must be refreshed before the next call
     const HistBuf &out() const { return stage.back(); }
     long long out_len() const { return lens.back(); }
 };
@@ -119,6 +120,8 @@ struct WfmCore {
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+    void tail_jobs(std::vector<TailJob> &jobs) const;
+    long long last_n = 0;
 };
 
 // ---- FFT::fftSpectrum ----

@@ -180,7 +180,12 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
     }
     PG_HIP(hipEventRecord(tm.ev[5], stream_));
-    if (int rc = dec_.save_tails(stream_)) return rc;
+    {  // one launch refreshes every history head-room for the next call
+        std::vector<TailJob> jobs;
+        dec_.tail_jobs(jobs);
+        if (wfm) wfmc_.tail_jobs(jobs);
+        if (int rc = run_save_tails(stream_, jobs, C)) return rc;
+    }
     PG_HIP(hipEventRecord(tm.ev[6], stream_));
     osc_.advance(n);
     last_audio_n = (uint64_t)nd;

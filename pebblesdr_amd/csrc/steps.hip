@@ -203,7 +203,11 @@ int pebblegpu_decimator_process(pebblegpu_decimator *d, const double *in, double
     if (int rc = d->dec.run(d->stream, d->d_in, (long long)n, false, (long long)n, d->osc)) return rc;
     const long long no = d->dec.out_len();
     if (int rc = d->down(out, d->dec.out().data(), (size_t)no)) return rc;
-    if (int rc = d->dec.save_tails(d->stream)) return rc;
+    {
+        std::vector<pg::TailJob> jobs;
+        d->dec.tail_jobs(jobs);
+        if (int rc = pg::run_save_tails(d->stream, jobs, 1)) return rc;
+    }
     PG_HIP(hipStreamSynchronize(d->stream));
     *n_out = (uint32_t)no;
     return 0;
@@ -339,7 +343,14 @@ int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const d
     if (int rc = d->up(d->d_in, in, (size_t)n)) return rc;
     int rc;
     if (d->mode == PEBBLEGPU_DM_AM) rc = d->am.run(d->stream, d->d_in, n, d->d_out, n, n);
-    else rc = d->wfm.run(d->stream, d->d_in, n, d->d_out, n, n);
+    else {
+        rc = d->wfm.run(d->stream, d->d_in, n, d->d_out, n, n);
+        if (!rc) {
+            std::vector<pg::TailJob> jobs;
+            d->wfm.tail_jobs(jobs);
+            rc = pg::run_save_tails(d->stream, jobs, 1);
+        }
+    }
     if (rc) return rc;
     if (int rc2 = d->down(d->hd.data(), d->d_out, (size_t)n)) return rc2;
     *out = d->hd.data();
