@@ -82,6 +82,46 @@ def cpu_baseline(seconds_budget=12.0):
             "sample": "%d samples (%d super-frames) of the same 20 Msps WFM+spectrum workload, %.1f s, oracle/ scalar fp64" % (done, done // len(x), el)}
 
 
+def timed_steps(step, barrier, steps, dist):
+    """barrier + device sync, exactly `steps` steps, barrier + device sync; MAX of the elapsed time over ranks."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def control_plane_rehearsal(args, rank, world, dist):
+    n = args.superframes * 131072
+    shard = shard_streams(world, rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), barrier, args.steps, dist)
+    if dist is not None:
+        import torch
+        owned = [None] * world
+        dist.all_gather_object(owned, shard)
+    else:
+        owned = [shard]
+    if rank == 0:
+        print(json.dumps({"metric": "control-plane rehearsal (no GPU work)", "n_gpus": world, "steps": args.steps,
+                          "value": round(aggregate_msps(n * args.steps, world, elapsed), 2), "unit": "Msamples/s",
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "weak", "streams_by_rank": owned}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +129,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--superframes", type=int, default=256, help="super-frames (131072 samples) per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--control-plane-only", action="store_true",
+                    help="CPU rehearsal of the N>1 launch path (rendezvous, barriers, max-over-ranks, aggregation): "
+                         "the GPU step is replaced by a rank-dependent sleep; used by tests/test_multirank_gloo.py")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,6 +143,9 @@ def main():
         import torch.distributed as dist  # control plane only: barrier + max of a CPU scalar (gloo)
         dist.init_process_group(backend="gloo")
     assert world == args.gpus or world == 1, "launch one rank per GPU (torch.distributed.run --nproc-per-node N)"
+
+    if args.control_plane_only:
+        return control_plane_rehearsal(args, rank, world, dist)
 
     import pebblesdr_amd as P
     L = P.load_library()
@@ -127,19 +173,13 @@ def main():
     rx.synchronize()
 
     spec_ms, chain_ms = [], []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def step():
         rx.process_device(dbuf.ptr, n)
         spec_ms.append(rx.last_ms(1))          # HIP events on the library's stream, around the spectrum kernel
         chain_ms.append(rx.last_ms(0) - spec_ms[-1])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    elapsed = timed_steps(step, barrier, args.steps, dist)
 
     if rank == 0:
         frames = n // NF
