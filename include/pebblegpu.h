@@ -127,6 +127,9 @@ const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *
  * call; 1 spectrum kernel; 2 mixer+first-decimator kernel; 3 remaining decimator stages; 4 FastFIR;
  * 5 demod. */
 int pebblegpu_receiver_last_ms(const pebblegpu_receiver *rx, int which, float *ms);
+/* the same, averaged over the last `last_k` process calls (the library keeps events for 64): lets a caller queue calls
+ * back to back without a host sync per call and read the kernel times afterwards */
+int pebblegpu_receiver_mean_ms(const pebblegpu_receiver *rx, int which, uint32_t last_k, float *ms);
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);
 
 /* Host single-frame path with the reference's callback shape:
@@ -158,9 +161,10 @@ int pebblegpu_decimator_destroy(pebblegpu_decimator *d);
 int pebblegpu_decimator_build_chain(pebblegpu_decimator *d, uint32_t sample_rate_in, uint32_t protect_bw,
                                     uint32_t sample_rate_out, float *achieved_rate);
 int pebblegpu_decimator_dec_by2_stages(const pebblegpu_decimator *d, uint32_t *stages);
-/* quint32 Decimator::process(CPX *in, CPX *out, quint32 n), pebblelib/decimator.h:238.  Streams with exact
- * history; a frame shorter than a stage's tap count is NOT degraded to sample dropping (the reference's
- * fallback, decimator.cpp:602-625, reads indeterminate memory) -- see DESIGN.md section 6. */
+/* quint32 Decimator::process(CPX *in, CPX *out, quint32 n), pebblelib/decimator.h:238.  n must be a multiple of
+ * the total decimation.  Streams with exact history for any such n: a frame shorter than a stage's tap count is NOT
+ * degraded to sample dropping (the reference's fallback, decimator.cpp:602-625, reads indeterminate memory) --
+ * see DESIGN.md section 4. */
 int pebblegpu_decimator_process(pebblegpu_decimator *d, const double *in, double *out, uint32_t n, uint32_t *n_out);
 
 typedef struct pebblegpu_fastfir pebblegpu_fastfir;

@@ -17,7 +17,7 @@ SYMBOLS = [
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
-    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
+    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_mixer_create", "pebblegpu_mixer_destroy", "pebblegpu_mixer_set_frequency", "pebblegpu_mixer_process",
     "pebblegpu_decimator_create", "pebblegpu_decimator_destroy", "pebblegpu_decimator_build_chain",
     "pebblegpu_decimator_dec_by2_stages", "pebblegpu_decimator_process",
@@ -81,6 +81,7 @@ def _declare(L):
     L.pebblegpu_receiver_spectrum.restype = vp
     L.pebblegpu_receiver_spectrum.argtypes = [vp, C.POINTER(u64)]
     L.pebblegpu_receiver_last_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    L.pebblegpu_receiver_mean_ms.argtypes = [vp, i32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_synchronize.argtypes = [vp]
     L.pebblegpu_process_iq.argtypes = [vp, dp, C.c_uint16, dp, C.POINTER(u32), dp]
     # stand-alone steps
@@ -238,6 +239,11 @@ class ReceiverBank:
     def last_ms(self, which=0):
         ms = C.c_float()
         check(self.L, self.L.pebblegpu_receiver_last_ms(self.h, which, C.byref(ms)))
+        return ms.value
+
+    def mean_ms(self, which=0, last_k=1):
+        ms = C.c_float()
+        check(self.L, self.L.pebblegpu_receiver_mean_ms(self.h, which, last_k, C.byref(ms)))
         return ms.value
 
     def audio(self):

@@ -32,6 +32,12 @@ inline void launch(void (*kernel)(KA...), dim3 grid, dim3 block, hipStream_t str
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, static_cast<KA>(args)...);
 }
 
+template <class... KA, class... A>
+inline void launch_lds(void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, A... args)
+{
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, static_cast<KA>(args)...);
+}
+
 // ---- small complex helpers on float2 ----
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {

@@ -2,6 +2,7 @@
 // This is the only translation unit that instantiates kernels.
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include "kernels_demod.h"
 #include "kernels_fastfir.h"
 #include "kernels_frontend.h"
@@ -92,11 +93,17 @@ int make_twiddles(int n, float2 **d_tw)
 // ------------------------------------------------------------------------------------------------
 int OscBank::init(uint32_t channels, double sample_rate)
 {
+    static_assert(sizeof(OscBank::Dyn) == kChanOscDynBytes && offsetof(ChanOsc, inc) == kChanOscDynBytes, "ChanOsc layout");
     C = channels;
     fs = sample_rate;
     ctl.assign(C, Ctl());
     h_osc.assign(C, ChanOsc());
+    for (int i = 0; i < 2; i++) {
+        PG_HIP(hipHostMalloc((void **)&h_dyn[i], sizeof(Dyn) * C, 0));
+        PG_HIP(hipEventCreate(&h_done[i]));
+    }
     PG_HIP(hipMalloc((void **)&d_osc, sizeof(ChanOsc) * C));
+    PG_HIP(hipMemset(d_osc, 0, sizeof(ChanOsc) * C));
     std::vector<float> amp(kAmpTab);
     design::mixer_amplitudes(amp.data(), kAmpTab, &a_inf);
     PG_HIP(hipMalloc((void **)&d_amp, sizeof(float) * kAmpTab));
@@ -105,6 +112,12 @@ int OscBank::init(uint32_t channels, double sample_rate)
 }
 void OscBank::release()
 {
+    for (int i = 0; i < 2; i++) {
+        if (h_dyn[i]) (void)hipHostFree(h_dyn[i]);
+        if (h_done[i]) (void)hipEventDestroy(h_done[i]);
+        h_dyn[i] = nullptr;
+        h_done[i] = nullptr;
+    }
     if (d_osc) (void)hipFree(d_osc);
     if (d_amp) (void)hipFree(d_amp);
     d_osc = nullptr;
@@ -121,24 +134,39 @@ void OscBank::retune(uint32_t ch, double f)
 }
 int OscBank::upload(hipStream_t s)
 {
+    // retuned channels: rebuild the constant part (phasor step tables) and upload the whole block, synchronously (rare)
     for (uint32_t ch = 0; ch < C; ch++) {
         Ctl &c = ctl[ch];
+        if (!c.dirty) continue;
         ChanOsc &o = h_osc[ch];
-        if (c.dirty) {
-            for (int d = 0; d < kMaxTaps; d++) {
-                double ph = (double)d * c.inc;
-                ph -= std::floor(ph);
-                o.step[d] = make_float2((float)std::cos(design::kTwoPi * ph), (float)std::sin(design::kTwoPi * ph));
-            }
-            o.inc = c.inc;
-            o.mix_on = (-c.freq) != 0 ? 1u : 0u;  // if (m_frequency == 0) return in;  (mixer.cpp:51-53)
-            c.dirty = false;
+        for (int d = 0; d < kMaxTaps; d++) {
+            double ph = (double)d * c.inc;
+            ph -= std::floor(ph);
+            o.step[d] = make_float2((float)std::cos(design::kTwoPi * ph), (float)std::sin(design::kTwoPi * ph));
         }
+        double ph = 512.0 * c.inc;
+        ph -= std::floor(ph);
+        o.step512 = make_float2((float)std::cos(design::kTwoPi * ph), (float)std::sin(design::kTwoPi * ph));
+        o.inc = c.inc;
+        o.mix_on = (-c.freq) != 0 ? 1u : 0u;  // if (m_frequency == 0) return in;  (mixer.cpp:51-53)
         o.phase0 = c.phase0;
-        o.n0 = (uint32_t)(c.n0 > (uint64_t)kAmpTab ? (uint64_t)kAmpTab : c.n0);
+        o.n0 = 0;
+        PG_HIP(hipMemcpyAsync(d_osc + ch, &o, sizeof(ChanOsc), hipMemcpyHostToDevice, s));
+        PG_HIP(hipStreamSynchronize(s));
+        c.dirty = false;
     }
-    PG_HIP(hipMemcpyAsync(d_osc, h_osc.data(), sizeof(ChanOsc) * C, hipMemcpyHostToDevice, s));
-    PG_HIP(hipStreamSynchronize(s));
+    // every call: phase and amplitude-transient position, 16 bytes per channel, from pinned ping-pong staging
+    const int cur = h_idx;
+    h_idx ^= 1;
+    PG_HIP(hipEventSynchronize(h_done[cur]));  // copy issued two uploads ago: finished long since, never waits in steady state
+    Dyn *hd = h_dyn[cur];
+    for (uint32_t ch = 0; ch < C; ch++) {
+        hd[ch].phase0 = ctl[ch].phase0;
+        hd[ch].n0 = (uint32_t)(ctl[ch].n0 > (uint64_t)kAmpTab ? (uint64_t)kAmpTab : ctl[ch].n0);
+        hd[ch].mix_on = h_osc[ch].mix_on;
+    }
+    PG_HIP(hipMemcpy2DAsync(d_osc, sizeof(ChanOsc), hd, sizeof(Dyn), sizeof(Dyn), C, hipMemcpyHostToDevice, s));
+    PG_HIP(hipEventRecord(h_done[cur], s));
     return 0;
 }
 void OscBank::advance(uint64_t n)
@@ -162,80 +190,107 @@ int run_mixer(hipStream_t s, const float2 *d_in, float2 *d_out, long long n, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// DecimCore
+// DecimCore: k_mix_dec1 (mixer + first merged stage) -> buf0 -> k_cascade (every later stage, fused) -> final
 // ------------------------------------------------------------------------------------------------
+static size_t mixdec_lds_bytes(const FirTaps &t)
+{
+    const int H = t.cic3 ? t.stride : t.ntaps - 1;
+    const int span = 256 * t.stride + H;
+    return (size_t)(span + span / t.stride + 2) * sizeof(float2);
+}
+
 int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain)
 {
     release();
     chain = c;
     C = channels;
     const size_t ns = chain.stages.size();
-    stage.assign(ns, HistBuf());
-    taps.resize(ns);
-    lens.assign(ns, 0);
-    std::vector<float> htaps(ns * kMaxTaps + 1, 0.f);
-    long long len = max_in;
-    for (size_t s = 0; s < ns; s++) {
-        const design::Stage &st = chain.stages[s];
-        len /= st.stride;
-        FirTaps &t = taps[s];
-        memset(&t, 0, sizeof(t));
-        t.ntaps = st.ntaps;
-        t.stride = (int)st.stride;
-        t.cic3 = st.ntaps == 0;
-        t.gain = (s + 1 == ns) ? last_gain : 1.f;
-        for (int p = 0; p < st.ntaps; p++) t.h[p] = htaps[s * kMaxTaps + p] = (float)design::halfband_taps(st.design)[p];
-        const int hist = (s + 1 < ns) ? chain.stages[s + 1].ntaps - 1 : last_hist;
-        if (int rc = stage[s].alloc((int)C, hist, len)) return rc;
+    if (ns - 1 > (size_t)kMaxCascade) return fail(PEBBLEGPU_E_UNSUPPORTED, "decimation chain has %zu stages; at most %d are built", ns, kMaxCascade + 1);
+    const design::Stage &s0 = chain.stages[0];
+    memset(&first, 0, sizeof(first));
+    first.ntaps = s0.ntaps;
+    first.stride = (int)s0.stride;
+    first.cic3 = s0.ntaps == 0;
+    first.gain = ns == 1 ? last_gain : 1.f;
+    for (int p = 0; p < s0.ntaps; p++) first.h[p] = (float)design::halfband_taps(s0.design)[p];
+    if (mixdec_lds_bytes(first) > 150 * 1024) return fail(PEBBLEGPU_E_UNSUPPORTED, "first-stage stride %u too wide for the LDS tile", s0.stride);
+    // the fused later stages
+    memset(&casc, 0, sizeof(casc));
+    casc.nst = (int)ns - 1;
+    casc.gain = last_gain;
+    long long halo0 = 0, prod = 1, later = 1;
+    for (size_t k = 1; k < ns; k++) {
+        const design::Stage &st = chain.stages[k];
+        casc.ntaps[k - 1] = st.ntaps;
+        casc.stride[k - 1] = (int)st.stride;
+        for (int p = 0; p < st.ntaps; p++) casc.h[k - 1][p] = (float)design::halfband_taps(st.design)[p];
+        halo0 += (long long)(st.ntaps - 1) * prod;  // look-back of the whole cascade, in stage-0 output samples
+        prod *= st.stride;
+        later *= st.stride;
     }
-    PG_HIP(hipMalloc((void **)&d_taps, sizeof(float) * htaps.size()));
-    PG_HIP(hipMemcpy(d_taps, htaps.data(), sizeof(float) * htaps.size(), hipMemcpyHostToDevice));
+    if (casc.nst > 0) {
+        // largest power-of-two tile of final outputs whose two ping-pong buffers fit comfortably (<= 48 KiB)
+        int outb = 256;
+        for (;; outb /= 2) {
+            long long c0 = outb, c1 = 0;
+            for (int k = casc.nst; k >= 1; k--) {
+                c1 = c0;
+                c0 = c0 * casc.stride[k - 1] + casc.ntaps[k - 1] - 1;
+            }
+            // c0 = stage-0 samples a tile reads, c1 = outputs of the first fused stage (the largest intermediate)
+            if ((c0 + c1) * (long long)sizeof(float2) <= 48 * 1024 || outb == 1) {
+                casc.outb = outb;
+                casc.lds_half = (int)c0;
+                casc_lds_bytes = (size_t)(c0 + c1) * sizeof(float2);
+                break;
+            }
+        }
+        if (casc_lds_bytes > 150 * 1024) return fail(PEBBLEGPU_E_UNSUPPORTED, "decimation cascade does not fit LDS");
+    }
+    const long long len0 = max_in / s0.stride;
+    if (ns == 1) {
+        if (int rc = buf0.alloc((int)C, last_hist, len0)) return rc;
+    } else {
+        if (halo0 > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "cascade look-back %lld too deep", halo0);
+        if (int rc = buf0.alloc((int)C, (int)halo0, len0)) return rc;
+        if (int rc = fin.alloc((int)C, last_hist, len0 / later)) return rc;
+    }
     PG_HIP(hipMalloc((void **)&d_hist_mixed, sizeof(float2) * kMaxTaps * C));
     PG_HIP(hipMemset(d_hist_mixed, 0, sizeof(float2) * kMaxTaps * C));
     return 0;
 }
 void DecimCore::release()
 {
-    for (auto &b : stage) b.release();
-    stage.clear();
-    if (d_taps) (void)hipFree(d_taps);
+    buf0.release();
+    fin.release();
     if (d_hist_mixed) (void)hipFree(d_hist_mixed);
-    d_taps = nullptr;
     d_hist_mixed = nullptr;
 }
 int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
                    hipEvent_t after_first)
 {
-    const size_t ns = chain.stages.size();
     if (n <= 0 || n % (long long)chain.total != 0)
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
-    long long len = n;
-    for (size_t k = 0; k < ns; k++) {
-        len /= taps[k].stride;
-        if (len > stage[k].cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-        // a stage whose output is shorter than its consumer's look-back cannot refresh that history from one call:
-        // this is where the reference degrades to unfiltered sample dropping (decimator.cpp:602-625)
-        if (len < stage[k].hist)
-            return fail(PEBBLEGPU_E_SIZE, "frame too short for this chain: stage %zu yields %lld samples, its consumer needs %d", k, len,
-                        stage[k].hist);
-        lens[k] = len;
-    }
-    launch(k_mix_dec1, dim3(cdiv(lens[0], 256), C), dim3(256), s, d_in, in_pitch, (int)shared_input, stage[0].data(), stage[0].pitch,
-           lens[0], (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed, (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, taps[0]);
+    len0 = n / first.stride;
+    if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+    launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), C), dim3(256), mixdec_lds_bytes(first), s, d_in, in_pitch, (int)shared_input, buf0.data(),
+               buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed, (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, first);
     launch(k_mix_tail, dim3(C), dim3(64), s, d_in, in_pitch, (int)shared_input, n, (const ChanOsc *)osc.d_osc, d_hist_mixed, (int)kMaxTaps,
-           (const float *)osc.d_amp, osc.a_inf, taps[0].ntaps, taps[0].stride, taps[0].cic3);
+           (const float *)osc.d_amp, osc.a_inf, first.ntaps, first.stride, first.cic3);
     if (after_first) PG_HIP(hipEventRecord(after_first, s));
-    for (size_t k = 1; k < ns; k++)
-        launch(k_fir_dec, dim3(cdiv(lens[k], 256), C), dim3(256), s, (const float2 *)stage[k - 1].data(), stage[k - 1].pitch, stage[k].data(),
-               stage[k].pitch, lens[k], taps[k].stride, (const float *)(d_taps + k * kMaxTaps), 0, (const int *)nullptr, taps[k].ntaps,
-               taps[k].gain, (const int *)nullptr);
+    len_out = len0;
+    if (casc.nst > 0) {
+        len_out = n / (long long)chain.total;
+        launch_lds(k_cascade, dim3(cdiv(len_out, casc.outb), C), dim3(256), casc_lds_bytes, s, (const float2 *)buf0.data(), buf0.pitch, fin.data(),
+                   fin.pitch, len_out, casc);
+    }
     PG_HIP(hipGetLastError());
     return 0;
 }
 void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
-    for (size_t k = 0; k < stage.size(); k++)
-        if (stage[k].hist > 0) jobs.push_back(TailJob{stage[k].data(), stage[k].pitch, lens[k], stage[k].hist, 0});
+    if (buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0});
+    if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0});
 }
 
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels)
@@ -250,7 +305,8 @@ int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t cha
         tj.job[i] = jobs[i];
         if (jobs[i].hist > maxh) maxh = jobs[i].hist;
     }
-    launch(k_save_tails, dim3(cdiv(maxh, 256), channels, (unsigned)jobs.size()), dim3(256), s, tj);
+    if (maxh > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "history of %d samples too deep for the tail refresh", maxh);
+    launch(k_save_tails, dim3(1, channels, (unsigned)jobs.size()), dim3(256), s, tj);
     PG_HIP(hipGetLastError());
     return 0;
 }
@@ -372,9 +428,6 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 {
     C = channels;
     rate = demod_rate;
-    if (int rc = a.alloc((int)C, 2, max_n)) return rc;
-    if (int rc = b.alloc((int)C, kMaxTaps, max_n)) return rc;
-    if (int rc = c.alloc((int)C, 0, max_n)) return rc;
     lp_on = rate >= 150000;  // demod_wfm.cpp:210
     const design::Biquad l = design::biquad_lowpass(75000, 1.0, rate);   // demod_wfm.cpp:164
     const double lpc[5] = {l.b0, l.b1, l.b2, l.a1, l.a2};
@@ -384,14 +437,28 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
     const design::Biquad br = design::biquad_notch(19000.0, 5, rate);    // demod_wfm.cpp:178
     const double brc[5] = {br.b0, br.b1, br.b2, br.a1, br.a2};
     fill_scan_section(dn.sec[1], kBiquadDf2, brc);
-    warm_lp = scan_warm_subchunks(lp.sec, 1, 1e-13);
-    warm_dn = scan_warm_subchunks(dn.sec, 2, 1e-13);
+    // samples are stored fp32 (eps 6e-8): a start-up residue below 1e-10 of the state is invisible
+    warm_lp = scan_warm_subchunks(lp.sec, 1, 1e-10);
+    warm_dn = scan_warm_subchunks(dn.sec, 2, 1e-10);
     const std::vector<double> h = design::fir_lowpass(0, 1.0, 60.0, 15000.0, 1.4 * 15000.0, rate);  // demod_wfm.cpp:175
     ntaps = (int)h.size();
     std::vector<float> hf(kMaxTaps, 0.f);
     for (size_t i = 0; i < h.size(); i++) hf[i] = (float)h[i];
     PG_HIP(hipMalloc((void **)&d_taps, sizeof(float) * kMaxTaps));
     PG_HIP(hipMemcpy(d_taps, hf.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
+    // one fused kernel when both warm-ups fit its LDS budget (they do at every rate the WFM chain produces);
+    // otherwise the exact sequential multi-kernel path below
+    fused = warm_lp > 0 && warm_dn > 0 && warm_lp * kSub <= kWfmMaxWarm && warm_dn * kSub <= kWfmMaxWarm;
+    if (fused) {
+        for (int i = 0; i < 2; i++) {
+            PG_HIP(hipMalloc((void **)&d_state[i], sizeof(WfmState) * C));
+            PG_HIP(hipMemset(d_state[i], 0, sizeof(WfmState) * C));
+        }
+        return 0;
+    }
+    if (int rc = a.alloc((int)C, 2, max_n)) return rc;
+    if (int rc = b.alloc((int)C, kMaxTaps, max_n)) return rc;
+    if (int rc = c.alloc((int)C, 0, max_n)) return rc;
     for (int i = 0; i < 2; i++) {
         PG_HIP(hipMalloc((void **)&d_lp_state[i], sizeof(double) * 4 * C));
         PG_HIP(hipMemset(d_lp_state[i], 0, sizeof(double) * 4 * C));
@@ -403,39 +470,52 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 void WfmCore::release()
 {
     a.release(); b.release(); c.release();
-    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1]};
+    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_state[0], d_state[1]};
     for (void *q : p) if (q) (void)hipFree(q);
     d_taps = nullptr;
     d_lp_state[0] = d_lp_state[1] = d_dn_state[0] = d_dn_state[1] = nullptr;
+    d_state[0] = d_state[1] = nullptr;
 }
 int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
 {
-    if (n > a.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-    if (n < b.hist) return fail(PEBBLEGPU_E_SIZE, "WFM demod needs at least %d samples per call", b.hist);
-    const long long nsub = (n + kSub - 1) / kSub;
-    const int spb = 2;  // output sub-chunks per workgroup in chunk-parallel mode (each also re-runs warm_* before them)
-    if (lp_on) {
-        const unsigned gx = warm_lp < 0 ? 1u : cdiv(nsub, spb);
-        launch(k_iir_scan<0, 1>, dim3(gx, C), dim3(64), s, in, in_pitch, a.data(), a.pitch, n, lp, (const double *)d_lp_state[parity],
-               d_lp_state[parity ^ 1], warm_lp < 0 ? (int)nsub : spb, warm_lp, (const int *)nullptr);
-    } else {
-        launch(k_copy, dim3(cdiv(n, 256), C), dim3(256), s, in, in_pitch, a.data(), a.pitch, n);
+    if (n < kMaxTaps) return fail(PEBBLEGPU_E_SIZE, "WFM demod needs at least %d samples per call", kMaxTaps);
+    last_n = n;
+    if (fused) {
+        WfmParams wp;
+        memset(&wp, 0, sizeof(wp));
+        wp.lp = lp.sec[0];
+        wp.dn[0] = dn.sec[0];
+        wp.dn[1] = dn.sec[1];
+        wp.lp_on = lp_on ? 1 : 0;
+        wp.ntaps = ntaps;
+        wp.warm_lp = warm_lp * kSub;
+        wp.warm_dn = warm_dn * kSub;
+        wp.gain = 0.25f;  // FMDEMOD_GAIN, demod_wfm.cpp:51
+        launch(k_wfm_mono, dim3(cdiv(n, kSub), C), dim3(256), s, in, in_pitch, out, out_pitch, n, wp, (const float *)d_taps,
+               (const WfmState *)d_state[parity], d_state[parity ^ 1]);
+        parity ^= 1;
+        PG_HIP(hipGetLastError());
+        return 0;
     }
+    if (n > a.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+    const long long nsub = (n + kSub - 1) / kSub;
+    // slow poles: one workgroup per channel walks the call sequentially with the exact carried state
+    if (lp_on)
+        launch(k_iir_scan<0, 1>, dim3(1, C), dim3(64), s, in, in_pitch, a.data(), a.pitch, n, lp, (const double *)d_lp_state[0], d_lp_state[0],
+               (int)nsub, -1, (const int *)nullptr);
+    else
+        launch(k_copy, dim3(cdiv(n, 256), C), dim3(256), s, in, in_pitch, a.data(), a.pitch, n);
     launch(k_discrim, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)a.data(), a.pitch, b.data(), b.pitch, n, 0.25f);  // FMDEMOD_GAIN
     launch(k_fir_dec, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)b.data(), b.pitch, c.data(), c.pitch, n, 1, (const float *)d_taps, 0,
            (const int *)nullptr, ntaps, 1.0f, (const int *)nullptr);
-    {
-        const unsigned gx = warm_dn < 0 ? 1u : cdiv(nsub, spb);
-        launch(k_iir_scan<1, 2>, dim3(gx, C), dim3(64), s, (const float2 *)c.data(), c.pitch, out, out_pitch, n, dn,
-               (const double *)d_dn_state[parity], d_dn_state[parity ^ 1], warm_dn < 0 ? (int)nsub : spb, warm_dn, (const int *)nullptr);
-    }
-    parity ^= 1;
-    last_n = n;
+    launch(k_iir_scan<1, 2>, dim3(1, C), dim3(64), s, (const float2 *)c.data(), c.pitch, out, out_pitch, n, dn, (const double *)d_dn_state[0],
+           d_dn_state[0], (int)nsub, -1, (const int *)nullptr);
     PG_HIP(hipGetLastError());
     return 0;
 }
 void WfmCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
+    if (fused) return;
     jobs.push_back(TailJob{a.data(), a.pitch, last_n, a.hist, 0});
     jobs.push_back(TailJob{b.data(), b.pitch, last_n, b.hist, 0});
 }

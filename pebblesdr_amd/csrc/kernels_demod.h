@@ -142,6 +142,156 @@ static __global__ __launch_bounds__(64) void k_iir_scan(const float2 *__restrict
     }
 }
 
+// Demod_WFM::processDataMono (application/demod/demod_wfm.cpp:207-232) in ONE kernel, one wave per 512 output samples:
+//   biquad low-pass on I and Q (if rate >= 150 kHz)  ->  0.25*atan2 discriminator  ->  75-tap CFir  ->  de-emphasis  ->  19 kHz notch
+// The two recurrences are wave scans (scan_sub).  A workgroup that does not start at the call boundary rebuilds their
+// state by running the filters over a warm-up stretch from zero state (host sizes it so pole^samples < 1e-13):
+//   notch/de-emphasis warm-up Wd, then 74 samples of FIR look-back + 1 of discriminator look-back, then the low-pass
+//   warm-up Wl  ->  up to Wd + Wl + 512 + 75 input samples per 512 outputs, all kept in LDS.
+// At the call boundary the exact state of the previous call is used instead: recurrence states, the last low-passed
+// sample and the last 74 discriminator outputs (ping-pong buffers: block 0 reads while the last block writes).
+// grid (ceil(n/512), C), block 256 (wave 0 scans I and later the audio, wave 1 scans Q; all four do the rest).
+struct WfmParams {
+    ScanSection lp;       // biquad low-pass (applied to I and Q independently)
+    ScanSection dn[2];    // de-emphasis, notch
+    int lp_on, ntaps;     // FIR length (<= 75)
+    int warm_lp, warm_dn; // warm-up lengths in samples (multiples of kSub)
+    float gain;           // FMDEMOD_GAIN
+    int pad_;
+};
+struct WfmState {         // per channel
+    double lp[2][2];      // [component][2]
+    double dn[2][2];      // [section][2]
+    float2 lp_last;       // last low-passed sample of the previous call (discriminator look-back)
+    float dtail[kMaxTaps];  // last ntaps-1 discriminator outputs, oldest first (FIR look-back)
+    float pad_[2];
+};
+
+constexpr int kWfmMaxWarm = 4 * kSub;  // per recurrence
+
+static __global__ __launch_bounds__(256) void k_wfm_mono(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ out,
+                                                         long long out_pitch, long long n, WfmParams wp,
+                                                         const float *__restrict__ taps, const WfmState *__restrict__ st_in,
+                                                         WfmState *__restrict__ st_out)
+{
+    constexpr int kPad = kSub + kSub / kSeg + 1;
+    constexpr int kLp = kWfmMaxWarm + kSub + kMaxTaps;   // low-passed samples a block may keep
+    __shared__ float re[kPad], im[kPad];
+    __shared__ float2 lpbuf[kLp];
+    __shared__ float dbuf[kLp + 8 * 256];                 // + slack so the register-blocked FIR may read past the end
+    __shared__ float fbuf[kWfmMaxWarm + kSub];
+    __shared__ float ht[kMaxTaps];
+    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = wp.ntaps;
+    const float2 *x = in + (long long)c * in_pitch;
+    const WfmState *si = st_in + c;
+    const long long s = (long long)blockIdx.x * kSub;                    // first output of this block
+    const long long e = (s + kSub) < n ? (s + kSub) : n;                 // one past its last output
+    const bool last_block = e == n;
+    if (tid < kMaxTaps) ht[tid] = tid < T ? taps[tid] : 0.f;
+
+    long long ds = s - wp.warm_dn;                                       // where the de-emphasis/notch run starts
+    const bool dn_exact = ds <= 0;
+    if (ds < 0) ds = 0;
+    const long long d0 = ds - (T - 1);                                   // first discriminator sample the FIR reads (may be < 0)
+    long long lk = d0 - 1;                                               // first low-passed sample kept (discriminator look-back)
+    if (lk < 0) lk = 0;
+    long long ls = lk - wp.warm_lp;                                      // where the low-pass run starts
+    const bool lp_exact = ls <= 0 || !wp.lp_on;
+    if (ls < 0 || !wp.lp_on) ls = wp.lp_on ? 0 : lk;
+
+    // ---- 1. low-pass over [ls, e), keeping [lk, e) in lpbuf.  Wave 0 scans I, wave 1 scans Q. ----
+    double q0 = 0, q1 = 0;  // biquad state of this wave's component
+    if (lp_exact && wp.lp_on && wave < 2) { q0 = si->lp[wave][0]; q1 = si->lp[wave][1]; }
+    for (long long off = ls; off < e; off += kSub) {
+        const int nv = (int)((e - off) < kSub ? (e - off) : kSub);
+        for (int j = tid; j < nv; j += 256) {
+            const float2 v = x[off + j];
+            re[spad(j)] = v.x;
+            im[spad(j)] = v.y;
+        }
+        __syncthreads();
+        if (wp.lp_on) {
+            if (wave == 0) scan_sub(wp.lp, re, nv, q0, q1, lane);
+            else if (wave == 1) scan_sub(wp.lp, im, nv, q0, q1, lane);
+        }
+        __syncthreads();
+        for (int j = tid; j < nv; j += 256) {
+            const long long idx = off + j;
+            if (idx >= lk) lpbuf[idx - lk] = make_float2(re[spad(j)], im[spad(j)]);
+        }
+        __syncthreads();
+    }
+    // ---- 2. discriminator over [max(d0,0), e); older samples come from the previous call's tail ----
+    const int nd = (int)(e - d0);                                        // dbuf[i] <-> discriminator sample d0 + i
+    for (int i = tid; i < nd; i += 256) {
+        const long long idx = d0 + i;
+        float v;
+        if (idx < 0) {
+            v = si->dtail[(T - 1) + idx];
+        } else {
+            const float2 c0 = lpbuf[idx - lk];
+            const float2 c1 = idx == 0 ? si->lp_last : lpbuf[idx - 1 - lk];
+            v = wp.gain * atan2f(c1.x * c0.y - c0.x * c1.y, c1.x * c0.x + c1.y * c0.y);  // demod_wfm.cpp:217
+        }
+        dbuf[i] = v;
+    }
+    __syncthreads();
+    // ---- 3. CFir over [ds, e): y[i] = sum_p d[i - (T-1) + p] * h[p]; 10 outputs per work-item in flight ----
+    const int nf = (int)(e - ds);
+    {
+        constexpr int RB = (kWfmMaxWarm + kSub) / 256;  // 10
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; r++) acc[r] = 0.f;
+        const float *dp = dbuf + tid;
+        for (int p = 0; p < T; p++) {
+            const float h = ht[p];
+#pragma unroll
+            for (int r = 0; r < RB; r++) acc[r] = fmaf(dp[p + 256 * r], h, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+            if (tid + 256 * r < nf) fbuf[tid + 256 * r] = acc[r];
+    }
+    __syncthreads();
+    // ---- 4. de-emphasis + notch over [ds, e) on wave 0, emitting [s, e) ----
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (dn_exact) { a0 = si->dn[0][0]; a1 = si->dn[0][1]; b0 = si->dn[1][0]; b1 = si->dn[1][1]; }
+    float2 *y = out + (long long)c * out_pitch;
+    for (long long off = ds; off < e; off += kSub) {
+        const int nv = (int)((e - off) < kSub ? (e - off) : kSub);
+        for (int j = tid; j < nv; j += 256) re[spad(j)] = fbuf[off - ds + j];
+        __syncthreads();
+        if (wave == 0) {
+            scan_sub(wp.dn[0], re, nv, a0, a1, lane);
+            scan_sub(wp.dn[1], re, nv, b0, b1, lane);
+        }
+        __syncthreads();
+        if (off + nv > s) {
+            for (int j = tid; j < nv; j += 256) {
+                const long long idx = off + j;
+                if (idx >= s) {
+                    const float v = re[spad(j)];
+                    y[idx] = make_float2(v, v);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 5. the block that reaches the end of the call leaves the exact state for the next one ----
+    if (last_block) {
+        WfmState *so = st_out + c;
+        if (lane == 0 && wave < 2) { so->lp[wave][0] = q0; so->lp[wave][1] = q1; }
+        if (tid == 0) {
+            so->dn[0][0] = a0; so->dn[0][1] = a1; so->dn[1][0] = b0; so->dn[1][1] = b1;
+            so->lp_last = lpbuf[(n - 1) - lk];
+        }
+        for (int j = tid; j < T - 1; j += 256) so->dtail[j] = dbuf[(n - (T - 1) + j) - d0];
+    }
+}
+
 // FM discriminator, demod_wfm.cpp:214-220: out = gain * atan2(I1*Q0 - I0*Q1, I1*I0 + Q1*Q0), written to
 // both components.  in[-1] is the previous call's last sample (head-room 1).  grid (ceil(n/256), C).
 static __global__ __launch_bounds__(256) void k_discrim(const float2 *__restrict__ in, long long in_pitch,

@@ -46,76 +46,150 @@ static __global__ __launch_bounds__(256) void k_mixer(const float2 *__restrict__
     }
 }
 
-// Fused mixer + first decimation stage.  One work-item per output sample o:
+// Fused mixer + first decimation stage, LDS-tiled.  A workgroup produces 256 consecutive outputs:
 //   halfband:  y[o] = sum_p m[o*S + p - (T-1)] * h[p]          (decimator.cpp:637-648, vDSP_zrdesampD)
 //   CIC3:      y[o] = .125*(m[oS+1] + m[(o-1)S] + 3*(m[(o-1)S+1] + m[oS]))   (decimator.cpp:727-731)
-// with m[i] = osc(i)*x[i] for i >= 0 and m[i] = hist[T-1+i] (mixed samples kept from the previous call).
-// Only taps that are non-zero are mixed at all, so for stride > taps most input samples cost nothing.
-// grid (ceil(n_out/256), C).
+// with m[i] = osc(i)*x[i] for i >= 0 and, for i < 0, the mixed samples kept from the previous call (`hist`).
+// The 256*S + look-back input samples are fetched once with 16-byte coalesced loads, rotated by the oscillator
+// on the way in (one exact fp64-phase sincos per lane every fourth sweep, a constant rotation exp(j*2*pi*512*inc)
+// in between) and parked in LDS with one pad slot per S samples, so the stride-S tap reads are conflict-free.
+// grid (ceil(n_out/256), C); dynamic LDS = pad(256*S + look-back) float2.
 static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restrict__ in, long long in_pitch, int shared_input,
-                                                   float2 *__restrict__ out, long long out_pitch, long long n_out,
-                                                   const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
-                                                   int hist_pitch, const float *__restrict__ amp_tab, float a_inf,
-                                                   FirTaps taps)
+                                                          float2 *__restrict__ out, long long out_pitch, long long n_out,
+                                                          const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
+                                                          int hist_pitch, const float *__restrict__ amp_tab, float a_inf,
+                                                          FirTaps taps)
 {
-    const int c = blockIdx.y;
-    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (o >= n_out) return;
+    HIP_DYNAMIC_SHARED(float2, tile)
+    __shared__ float ht[kMaxTaps];  // taps out of the kernel-argument segment: the tap loop must not wait on scalar loads
+    const int c = blockIdx.y, t = threadIdx.x;
     const ChanOsc *oc = &osc[c];
     const float2 *x = in + (shared_input ? 0 : (long long)c * in_pitch);
     const float2 *hs = hist + (long long)c * hist_pitch;
-    const int S = taps.stride;
-    float2 acc;
-    if (taps.cic3) {
-        // history slots: hist[0] = m[-S] (even of the previous stride), hist[1] = m[-S+1] (odd)
-        const long long ie = o * S;
-        const float2 p0 = oc->mix_on ? cis_cycles(oc->phase0 + (double)(ie + 1) * oc->inc) : make_float2(1.f, 0.f);
-        float2 ev = x[ie], od = x[ie + 1], pev, pod;
-        if (oc->mix_on) {
-            ev = cmul(cscale(p0, osc_amp(amp_tab, a_inf, oc->n0, ie)), ev);
-            od = cmul(cscale(cmul(p0, oc->step[1]), osc_amp(amp_tab, a_inf, oc->n0, ie + 1)), od);
-        }
-        if (o == 0) {
-            pev = hs[0];
-            pod = hs[1];
+    const int S = taps.stride, T = taps.ntaps;
+    if (t < kMaxTaps) ht[t] = t < T ? taps.h[t] : 0.f;
+    const int ls = __ffs(S) - 1;                      // S is a power of two
+    const int H = taps.cic3 ? S : T - 1;              // look-back in input samples (even)
+    const long long o0 = (long long)blockIdx.x * 256;
+    const int nout = (int)((n_out - o0) < 256 ? (n_out - o0) : 256);
+    const long long i0 = o0 * S - H;                  // input index of tile slot 0 (even)
+    const int span = nout * S + H;                    // even
+    const bool mix = oc->mix_on != 0;
+    const bool settled = oc->n0 >= (uint32_t)kAmpTab; // amplitude transient over: a_n == sqrt(0.95) to fp32
+    float2 ph = make_float2(1.f, 0.f);
+    int sweep = 0;
+    for (int v = t; v < span / 2; v += 256, sweep++) {
+        const long long i = i0 + 2 * v;
+        float2 a, b;
+        if (i < 0) {
+            if (taps.cic3) {  // only m[-S], m[-S+1] are ever read (hist[0], hist[1])
+                a = i == -S ? hs[0] : make_float2(0.f, 0.f);
+                b = i == -S ? hs[1] : make_float2(0.f, 0.f);
+            } else {
+                a = hs[H + i];
+                b = hs[H + i + 1];
+            }
+            sweep = -1;  // next sweep must take a fresh phase
         } else {
-            const long long ip = ie - S;
-            pev = x[ip];
-            pod = x[ip + 1];
-            if (oc->mix_on) {
-                const float2 q0 = cis_cycles(oc->phase0 + (double)(ip + 1) * oc->inc);
-                pev = cmul(cscale(q0, osc_amp(amp_tab, a_inf, oc->n0, ip)), pev);
-                pod = cmul(cscale(cmul(q0, oc->step[1]), osc_amp(amp_tab, a_inf, oc->n0, ip + 1)), pod);
+            const float4 xx = *reinterpret_cast<const float4 *>(x + i);
+            a = make_float2(xx.x, xx.y);
+            b = make_float2(xx.z, xx.w);
+            if (mix) {
+                if ((sweep & 3) == 0) ph = cis_cycles(oc->phase0 + (double)(i + 1) * oc->inc);
+                else ph = cmul(ph, oc->step512);
+                const float2 ph1 = cmul(ph, oc->step[1]);
+                const float aa = settled ? a_inf : osc_amp(amp_tab, a_inf, oc->n0, i);
+                const float ab = settled ? a_inf : osc_amp(amp_tab, a_inf, oc->n0, i + 1);
+                a = cmul(cscale(ph, aa), a);
+                b = cmul(cscale(ph1, ab), b);
             }
         }
+        const int s0 = 2 * v;
+        tile[s0 + (s0 >> ls)] = a;
+        tile[s0 + 1 + ((s0 + 1) >> ls)] = b;
+    }
+    __syncthreads();
+    if (t >= nout) return;
+    float2 acc;
+    if (taps.cic3) {
+        const int e = t * S;  // previous pair at e, e+1; current pair at e+S, e+S+1
+        const float2 pev = tile[e + (e >> ls)], pod = tile[e + 1 + ((e + 1) >> ls)];
+        const float2 ev = tile[e + S + ((e + S) >> ls)], od = tile[e + S + 1 + ((e + S + 1) >> ls)];
         acc.x = .125f * (od.x + pev.x + 3.0f * (pod.x + ev.x));
         acc.y = .125f * (od.y + pev.y + 3.0f * (pod.y + ev.y));
     } else {
-        const int T = taps.ntaps;
-        const long long i0 = o * S - (T - 1);           // time index of tap 0
-        const long long ib = i0 < 0 ? 0 : i0;            // first index that comes from this call's input
-        float2 p0 = make_float2(1.f, 0.f);
-        if (oc->mix_on) p0 = cis_cycles(oc->phase0 + (double)(ib + 1) * oc->inc);
-        acc = make_float2(0.f, 0.f);
-        for (int p = 0; p < T; p++) {
-            const float h = taps.h[p];
-            if (h == 0.f) continue;  // halfband zeros: uniform branch, nothing to load or mix
-            const long long i = i0 + p;
-            float2 m;
-            if (i < 0) {
-                m = hs[(T - 1) + i];
-            } else {
-                m = x[i];
-                if (oc->mix_on) {
-                    const float2 ph = cmul(p0, oc->step[(int)(i - ib)]);
-                    m = cmul(cscale(ph, osc_amp(amp_tab, a_inf, oc->n0, i)), m);
-                }
-            }
+        // halfband (T = 4k+3): non-zero taps sit at even p and at the odd centre (T-1)/2
+        const int e = t * S, cc = (T - 1) >> 1;
+        const float2 mc = tile[e + cc + ((e + cc) >> ls)];
+        acc = cscale(mc, ht[cc]);
+        for (int p = 0; p < T; p += 2) {
+            const float h = ht[p];
+            const float2 m = tile[e + p + ((e + p) >> ls)];
             acc.x = fmaf(m.x, h, acc.x);
             acc.y = fmaf(m.y, h, acc.y);
         }
     }
-    out[(long long)c * out_pitch + o] = cscale(acc, taps.gain);
+    out[(long long)c * out_pitch + o0 + t] = cscale(acc, taps.gain);
+}
+
+// All decimation stages after the first, fused: a workgroup produces `outb` final outputs, walking the
+// stages through two LDS ping-pong buffers (y_s[j] = sum_p y_{s-1}[j*S_s + p - (T_s-1)] * h_s[p]).  `in` points at the
+// first stage-0 output of this call; what lies before it (head-room) is the previous call's tail, deep enough for
+// the whole cascade: halo0 = sum_s (T_s - 1) * prod_{r<s} S_r.
+// grid (ceil(n_out/outb), C); dynamic LDS = (count_0 + count_1) float2.
+static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict__ in, long long in_pitch,
+                                                         float2 *__restrict__ out, long long out_pitch, long long n_out,
+                                                         CascadeParams cp)
+{
+    HIP_DYNAMIC_SHARED(float2, buf)
+    __shared__ float ht[kMaxCascade][64];  // taps out of the kernel-argument segment
+    const int c = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < kMaxCascade * 64; i += 256) {
+        const int s = i >> 6, p = i & 63;
+        ht[s][p] = (s < cp.nst && p < cp.ntaps[s]) ? cp.h[s][p] : 0.f;
+    }
+    const long long o0 = (long long)blockIdx.x * cp.outb;
+    const int nfin = (int)((n_out - o0) < cp.outb ? (n_out - o0) : cp.outb);
+    int cnt[kMaxCascade + 1];
+    long long first = o0;
+#pragma unroll
+    for (int s = kMaxCascade; s >= 0; s--) cnt[s] = 0;
+#pragma unroll
+    for (int s = kMaxCascade; s >= 1; s--) {
+        if (s == cp.nst) cnt[s] = nfin;
+        if (s <= cp.nst) {
+            cnt[s - 1] = cnt[s] * cp.stride[s - 1] + cp.ntaps[s - 1] - 1;
+            first = first * cp.stride[s - 1] - (cp.ntaps[s - 1] - 1);
+        }
+    }
+    const float2 *x = in + (long long)c * in_pitch + first;
+    float2 *src = buf, *dst = buf + cp.lds_half;
+    for (int j = t; j < cnt[0]; j += 256) src[j] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kMaxCascade; s++) {
+        if (s < cp.nst) {
+            const int S = cp.stride[s], T = cp.ntaps[s], ns = cnt[s + 1];
+            const bool last = s == cp.nst - 1;
+            const int cc = (T - 1) >> 1;  // halfband: even taps + the odd centre
+            for (int j = t; j < ns; j += 256) {
+                const float2 *w = src + j * S;
+                float2 acc = cscale(w[cc], ht[s][cc]);
+                for (int p = 0; p < T; p += 2) {
+                    const float h = ht[s][p];
+                    const float2 m = w[p];
+                    acc.x = fmaf(m.x, h, acc.x);
+                    acc.y = fmaf(m.y, h, acc.y);
+                }
+                if (last) out[(long long)c * out_pitch + o0 + j] = cscale(acc, cp.gain);
+                else dst[j] = acc;
+            }
+            __syncthreads();
+            float2 *tmp = src;
+            src = dst;
+            dst = tmp;
+        }
+    }
 }
 
 // Mixed-sample history for the next call: hist[c][j] = m[n - H + j], j < H (H = T-1, or for CIC3
@@ -184,14 +258,25 @@ static __global__ __launch_bounds__(256) void k_save_tail(float2 *__restrict__ d
     b[-hist + j] = b[n - hist + j];
 }
 
-// All history tails of a call in one launch.  grid (ceil(max hist/256), C, jobs).
+// All history tails of a call in one launch: buf[c][-hist + j] = buf[c][n - hist + j], j < hist, for every buffer.
+// n may be shorter than hist (then part of the old history is kept, shifted), so a workgroup first reads every value
+// it will write.  grid (1, C, jobs), hist <= 256*32.
 static __global__ __launch_bounds__(256) void k_save_tails(TailJobs jobs)
 {
-    const TailJob &t = jobs.job[blockIdx.z];
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= t.hist) return;
-    float2 *b = t.data + (long long)blockIdx.y * t.pitch;
-    b[-t.hist + j] = b[t.n - t.hist + j];
+    const TailJob &tj = jobs.job[blockIdx.z];
+    float2 *b = tj.data + (long long)blockIdx.y * tj.pitch;
+    float2 keep[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int j = threadIdx.x + 256 * k;
+        if (j < tj.hist) keep[k] = b[tj.n - tj.hist + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int j = threadIdx.x + 256 * k;
+        if (j < tj.hist) b[-tj.hist + j] = keep[k];
+    }
 }
 
 }  // namespace pg

@@ -8,11 +8,15 @@ namespace pg {
 // Mixer::processBlock (pebblelib/mixer.cpp:48-81) restated in closed form:
 //   osc_i = a_{n0+i} * exp(j*2*pi*(phase0 + (i+1)*inc)),  a_0 = 1, a_{k+1} = a_k*(1.95 - a_k^2)
 struct ChanOsc {
+    // --- first 16 bytes change every call (uploaded alone, asynchronously) ---
     double phase0;          // cycles; accumulated phase at the end of the previous call (0 after a retune)
-    double inc;             // cycles per sample = -f/Fs (the reference negates f, mixer.cpp:31)
     uint32_t n0;            // samples since the last retune, saturated at kAmpTab
     uint32_t mix_on;        // 0 => f == 0: Mixer returns its input untouched (mixer.cpp:51-53)
+    // --- the rest changes only on a retune ---
+    double inc;             // cycles per sample = -f/Fs (the reference negates f, mixer.cpp:31)
     float2 step[kMaxTaps];  // exp(j*2*pi*d*inc), d = 0..kMaxTaps-1, rounded from fp64
+    float2 step512;         // exp(j*2*pi*512*inc): advance of one 256-lane float4 sweep
+    float2 pad_;
 };
 
 struct FirTaps {
@@ -22,6 +26,18 @@ struct FirTaps {
     float gain; // applied to the output (gain restore on the last stage, receiver.cpp:935-938), else 1
     float h[kMaxTaps];
 };
+
+// later decimation stages fused in one kernel (k_cascade): taps live in the kernel-argument segment
+constexpr int kMaxCascade = 6;
+struct CascadeParams {
+    int nst, outb;            // fused stages, final outputs per workgroup
+    int lds_half, pad_;       // float2 slots of the first ping-pong buffer
+    float gain;               // applied to the final stage's output
+    int ntaps[kMaxCascade], stride[kMaxCascade];
+    float h[kMaxCascade][60];
+};
+
+constexpr size_t kChanOscDynBytes = 16;
 
 constexpr int kSeg = 8;               // consecutive samples one lane runs serially
 constexpr int kSub = 64 * kSeg;       // samples one wave scans at a time

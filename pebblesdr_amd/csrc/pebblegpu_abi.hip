@@ -149,16 +149,29 @@ int pebblegpu_receiver_synchronize(pebblegpu_receiver *h)
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
     return h->rx.sync();
 }
-int pebblegpu_receiver_last_ms(const pebblegpu_receiver *h, int which, float *ms)
+// 0 whole call; 1 spectrum; 2 mixer+first stage; 3 later stages; 4 FastFIR; 5 demod
+static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, float *ms)
 {
     if (!h || !ms || which < 0 || which > 5) return fail(PEBBLEGPU_E_INVALID, "bad argument");
     const pg::Timers &t = h->rx.tm;
-    // 0 whole call; 1 spectrum; 2 mixer+first stage; 3 later stages; 4 FastFIR; 5 demod
+    if (t.calls == 0) return fail(PEBBLEGPU_E_INVALID, "no call has been made yet");
+    if (last_k == 0) last_k = 1;
+    if (last_k > (uint32_t)pg::Timers::kRing) last_k = pg::Timers::kRing;
+    if ((uint64_t)last_k > t.calls) last_k = (uint32_t)t.calls;
     static const int a[6] = {0, 0, 1, 2, 3, 4}, b[6] = {6, 1, 2, 3, 4, 5};
-    PG_HIP(hipEventSynchronize(t.ev[6]));
-    PG_HIP(hipEventElapsedTime(ms, t.ev[a[which]], t.ev[b[which]]));
+    double sum = 0;
+    for (uint32_t k = 0; k < last_k; k++) {
+        const hipEvent_t *ev = t.ev[(t.calls - 1 - k) % pg::Timers::kRing];
+        float one = 0;
+        PG_HIP(hipEventSynchronize(ev[6]));
+        PG_HIP(hipEventElapsedTime(&one, ev[a[which]], ev[b[which]]));
+        sum += one;
+    }
+    *ms = (float)(sum / last_k);
     return 0;
 }
+int pebblegpu_receiver_last_ms(const pebblegpu_receiver *h, int which, float *ms) { return kernel_ms(h, which, 1, ms); }
+int pebblegpu_receiver_mean_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, float *ms) { return kernel_ms(h, which, last_k, ms); }
 int pebblegpu_process_iq(pebblegpu_receiver *h, const double *iq, uint16_t n, double *audio, uint32_t *n_audio,
                          double *spectrum_db)
 {

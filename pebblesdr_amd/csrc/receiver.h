@@ -43,14 +43,18 @@ struct OscBank {
     double fs = 0;
     uint32_t C = 0;
     std::vector<Ctl> ctl;
-    std::vector<ChanOsc> h_osc;
+    std::vector<ChanOsc> h_osc;               // host master copy
+    struct Dyn { double phase0; uint32_t n0, mix_on; };
+    Dyn *h_dyn[2] = {nullptr, nullptr};       // pinned staging of the per-call fields, ping-pong: no host sync per call
+    hipEvent_t h_done[2] = {nullptr, nullptr};
+    int h_idx = 0;
     ChanOsc *d_osc = nullptr;
     float *d_amp = nullptr;
     float a_inf = 0;
     int init(uint32_t channels, double sample_rate);
     void release();
     void retune(uint32_t ch, double f);           // Mixer::setFrequency, mixer.cpp:25-40
-    int upload(hipStream_t s);                     // refresh the device blocks (sync: host staging is pageable)
+    int upload(hipStream_t s);                     // refresh the device blocks (async, from pinned staging)
     void advance(uint64_t n);                      // after a call consumed n samples
 };
 
@@ -58,20 +62,21 @@ struct OscBank {
 struct DecimCore {
     design::Chain chain;
     uint32_t C = 0;
-    std::vector<HistBuf> stage;      // output of merged stage s
-    std::vector<FirTaps> taps;
-    std::vector<long long> lens;     // lengths produced by the last run
-    float *d_taps = nullptr;         // [stages][kMaxTaps]
+    FirTaps first;                   // stage 0 (fused with the mixer)
+    CascadeParams casc;              // stages 1.. (one fused kernel)
+    size_t casc_lds_bytes = 0;
+    HistBuf buf0, fin;               // stage-0 output (head-room = cascade look-back), final output (absent for 1-stage chains)
+    long long len0 = 0, len_out = 0; // lengths produced by the last run
     float2 *d_hist_mixed = nullptr;  // [C][kMaxTaps]: mixed-sample history of stage 0
     // last_hist: head-room of the final buffer (what the consumer looks back at); last_gain: folded into the final stage
     int init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain);
     void release();
-    // runs all stages; n must be a multiple of chain.total and every stage must see >= its consumer's history
+    // n must be a multiple of chain.total; any such n streams exactly (no minimum frame length)
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
             hipEvent_t after_first = nullptr);
     void tail_jobs(std::vector<TailJob> &jobs) const;  // after run(): what must be refreshed before the next call
-    const HistBuf &out() const { return stage.back(); }
-    long long out_len() const { return lens.back(); }
+    const HistBuf &out() const { return casc.nst > 0 ? fin : buf0; }
+    long long out_len() const { return len_out; }
 };
 
 // ---- CFastFIR ----
@@ -117,6 +122,8 @@ struct WfmCore {
     ScanParams<2> dn;
     int warm_lp = -1, warm_dn = -1, parity = 0;
     double *d_lp_state[2] = {nullptr, nullptr}, *d_dn_state[2] = {nullptr, nullptr};
+    bool fused = false;             // single-kernel path (k_wfm_mono); else the multi-kernel sequential fallback
+    struct WfmState *d_state[2] = {nullptr, nullptr};
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
@@ -137,8 +144,13 @@ struct SpectrumCore {
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out);
 };
 
+// HIP events around each kernel group, kept for the last kRing calls so a caller can run calls back to back
+// (no host sync per call) and read the per-kernel durations afterwards.
 struct Timers {
-    hipEvent_t ev[8] = {};
+    static constexpr int kRing = 64;
+    hipEvent_t ev[kRing][8] = {};
+    uint64_t calls = 0;
+    hipEvent_t *slot() { return ev[calls % kRing]; }
 };
 
 class Receiver {

@@ -29,7 +29,8 @@ int Receiver::create(const pebblegpu_config *cfg)
     if (nf < 256 || nf > 65535) return fail(PEBBLEGPU_E_INVALID, "frames_per_buffer must be 256..65535 (quint16, device_interfaces.h:32)");
     PG_HIP(hipSetDevice(device));
     PG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    for (auto &e : tm.ev) PG_HIP(hipEventCreate(&e));
+    for (auto &row : tm.ev)
+        for (auto &e : row) PG_HIP(hipEventCreate(&e));
 
     chain = design::build_chain((uint32_t)fs, wfm ? 200000u : 30000u, 0);  // receiver.cpp:195,213
     if (chain.stages.empty() || chain.stages.size() > (size_t)kMaxStages)
@@ -70,7 +71,8 @@ Receiver::~Receiver()
     audio.release();
     if (d_spec) (void)hipFree(d_spec);
     if (d_stage_in_) (void)hipFree(d_stage_in_);
-    for (auto &e : tm.ev) if (e) (void)hipEventDestroy(e);
+    for (auto &row : tm.ev)
+        for (auto &e : row) if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -156,37 +158,39 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         return fail(PEBBLEGPU_E_SIZE, "spectrum needs whole frames of %u samples within capacity", nf);
     if (int rc = apply_controls()) return rc;
     const long long in_pitch = (long long)n;
-    PG_HIP(hipEventRecord(tm.ev[0], stream_));
+    hipEvent_t *ev = tm.slot();
+    tm.calls++;
+    PG_HIP(hipEventRecord(ev[0], stream_));
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
         if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
         last_spec_frames = n / nf;
     }
-    PG_HIP(hipEventRecord(tm.ev[1], stream_));
+    PG_HIP(hipEventRecord(ev[1], stream_));
     if (!with_chain) {
-        for (int i = 2; i <= 6; i++) PG_HIP(hipEventRecord(tm.ev[i], stream_));
+        for (int i = 2; i <= 6; i++) PG_HIP(hipEventRecord(ev[i], stream_));
         return 0;
     }
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
-    if (int rc = dec_.run(stream_, d_iq, in_pitch, shared_input, (long long)n, osc_, tm.ev[2])) return rc;
-    PG_HIP(hipEventRecord(tm.ev[3], stream_));
+    if (int rc = dec_.run(stream_, d_iq, in_pitch, shared_input, (long long)n, osc_, ev[2])) return rc;
+    PG_HIP(hipEventRecord(ev[3], stream_));
     const long long nd = dec_.out_len();
     if (!wfm) {
         if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
-        PG_HIP(hipEventRecord(tm.ev[4], stream_));
+        PG_HIP(hipEventRecord(ev[4], stream_));
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
         if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
     } else {
-        PG_HIP(hipEventRecord(tm.ev[4], stream_));
+        PG_HIP(hipEventRecord(ev[4], stream_));
         if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
     }
-    PG_HIP(hipEventRecord(tm.ev[5], stream_));
+    PG_HIP(hipEventRecord(ev[5], stream_));
     {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
         if (wfm) wfmc_.tail_jobs(jobs);
         if (int rc = run_save_tails(stream_, jobs, C)) return rc;
     }
-    PG_HIP(hipEventRecord(tm.ev[6], stream_));
+    PG_HIP(hipEventRecord(ev[6], stream_));
     osc_.advance(n);
     last_audio_n = (uint64_t)nd;
     return 0;

@@ -66,13 +66,23 @@ def test_decimator_step(gpu_lib, oracle_mod, fs, bw, n):
         assert rel_rms(g, r) <= TOL
 
 
-def test_decimator_short_frame_is_an_error_not_a_degraded_filter(gpu_lib):
-    """Where the reference silently drops to unfiltered sample skipping (decimator.cpp:602-625) the library refuses."""
+def test_decimator_short_frames_stream_exactly(gpu_lib, oracle_mod):
+    """20 Msps / 30 kHz with the reference's default 2048-sample frames: the reference's later stages see fewer
+    samples than taps and silently drop to unfiltered sample skipping (decimator.cpp:602-625).  The library keeps
+    exact history instead, so 2048-sample frames give the same stream as the oracle fed 16384-sample frames
+    (where no stage falls back; the cascade is frame-invariant, test_oracle_pins.py)."""
     import pebblesdr_amd as P
-    d = P.Decimator(20000000, 2048)
-    d.buildDecimationChain(20000000, 30000)
+    fs, bw = 20000000, 30000
+    x = tones(fs, 48 * 2048, [(0.5, 1000.0), (0.3, fs / 5)]) + lcg_noise(48 * 2048, 3, 1e-2)
+    ref = oracle_mod.Decimator(fs, bw)
+    r = np.concatenate([ref.process(x[i:i + 16384]) for i in range(0, len(x), 16384)])
+    d = P.Decimator(fs, 2048)
+    d.buildDecimationChain(fs, bw)
+    g = np.concatenate([d.process(x[i:i + 2048]) for i in range(0, len(x), 2048)])
+    assert g.shape == r.shape and rel_rms(g, r) <= TOL
+    # a frame that is not a whole number of decimated samples is refused
     with pytest.raises(P.PebbleGpuError) as e:
-        d.process(np.zeros(2048, dtype=complex))
+        d.process(np.zeros(1000, dtype=complex))
     assert e.value.code == -5
 
 

@@ -230,6 +230,11 @@ static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = 
 static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memmove(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return 0; }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, int, hipStream_t)
+{
+    for (size_t r = 0; r < h; r++) memmove((char *)d + r * dp, (const char *)s + r * sp, w);
+    return 0;
+}
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 0; }
