@@ -82,6 +82,19 @@ def cpu_baseline(seconds_budget=12.0):
             "sample": "%d samples (%d super-frames) of the same 20 Msps WFM+spectrum workload, %.1f s, oracle/ scalar fp64" % (done, done // len(x), el)}
 
 
+def pmc_traffic(superframes):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate
+    runs, gfx950 half-count correction calibrated on known-size copies): tools/pmc_workload.py + tools/parse_traffic.py,
+    stored in profiles/.  Only valid for the batch size it was measured on (256 super-frames)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if superframes != 256 or not os.path.exists(path):
+        return None
+    try:
+        return int(round(json.load(open(path))["kernels"]["k_spectrum"]["hbm_bytes"]))
+    except Exception:
+        return None
+
+
 def timed_steps(step, barrier, steps, dist):
     """barrier + device sync, exactly `steps` steps, barrier + device sync; MAX of the elapsed time over ranks."""
     barrier()
@@ -181,6 +194,12 @@ def main():
     spec_ms = [rx.mean_ms(1, k_ev)]
     chain_ms = [rx.mean_ms(0, k_ev) - spec_ms[0]]
 
+    copy_gbps = None
+    if rank == 0:
+        try:
+            copy_gbps = round(P.binding.probe_copy_gbps(16, 1 << 30, 10, device), 1)  # measured float4 streaming copy, read+write
+        except Exception:
+            copy_gbps = None
     if rank == 0:
         frames = n // NF
         algo_bytes = frames * (8 * NF + 4 * BINS)  # 8*N + 4*bins per frame
@@ -203,7 +222,8 @@ def main():
                        "samples_per_step_per_gpu": n, "frames_per_buffer": NF, "spectrum_bins": BINS,
                        "parallelism": "independent channel per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": "k_spectrum<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.superframes),
+                         "measured_copy_peak_GBs": copy_gbps,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(k_ms, 4),
                          "rest_of_chain_ms": round(float(np.mean(chain_ms)), 4)},
         }

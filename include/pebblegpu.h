@@ -62,6 +62,9 @@ int pebblegpu_memcpy_h2d(int device, void *dst, const void *src, size_t bytes);
 int pebblegpu_memcpy_d2h(int device, void *dst, const void *src, size_t bytes);
 int pebblegpu_memset(int device, void *dst, int value, size_t bytes);
 int pebblegpu_device_synchronize(int device);
+/* Streaming-copy probe (read + write GB/s of a plain device copy with 16- or 8-byte lanes): the measured HBM ceiling
+ * the bench quotes next to the 8 TB/s datasheet peak. */
+int pebblegpu_probe_copy_gbps(int device, int lane_bytes, size_t bytes, int iters, float *gbps);
 /* normalizeIQ ingest helpers are a "next" row; not part of ABI v1. */
 
 /* ------------------------------------------------------------------------------------------------

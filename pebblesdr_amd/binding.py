@@ -13,7 +13,7 @@ _LIBNAME = "libpebblegpu.so"
 SYMBOLS = [
     "pebblegpu_last_error", "pebblegpu_abi_version", "pebblegpu_device_count",
     "pebblegpu_malloc", "pebblegpu_free", "pebblegpu_memcpy_h2d", "pebblegpu_memcpy_d2h", "pebblegpu_memset",
-    "pebblegpu_device_synchronize",
+    "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
@@ -69,6 +69,7 @@ def _declare(L):
     L.pebblegpu_memcpy_d2h.argtypes = [i32, vp, vp, C.c_size_t]
     L.pebblegpu_memset.argtypes = [i32, vp, i32, C.c_size_t]
     L.pebblegpu_device_synchronize.argtypes = [i32]
+    L.pebblegpu_probe_copy_gbps.argtypes = [i32, i32, C.c_size_t, i32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.pebblegpu_receiver_destroy.argtypes = [vp]
     L.pebblegpu_receiver_info.argtypes = [vp, C.POINTER(Info)]
@@ -128,6 +129,13 @@ def load_library(path=None):
 def check(L, rc):
     if rc != 0:
         raise PebbleGpuError(rc, (L.pebblegpu_last_error() or b"").decode("utf-8", "replace"))
+
+
+def probe_copy_gbps(lane_bytes=16, nbytes=1 << 30, iters=10, device=0, lib=None):
+    L = lib or load_library()
+    g = C.c_float()
+    check(L, L.pebblegpu_probe_copy_gbps(device, lane_bytes, nbytes, iters, C.byref(g)))
+    return g.value
 
 
 class DeviceBuffer:

@@ -180,6 +180,35 @@ void OscBank::advance(uint64_t n)
     }
 }
 
+// streaming-copy probe: the chip's practical HBM ceiling next to which the kernels are priced
+int probe_copy(int lane_bytes, size_t bytes, int iters, float *gbps)
+{
+    hipStream_t s;
+    hipEvent_t e0, e1;
+    void *a = nullptr, *b = nullptr;
+    PG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    PG_HIP(hipEventCreate(&e0));
+    PG_HIP(hipEventCreate(&e1));
+    PG_HIP(hipMalloc(&a, bytes));
+    PG_HIP(hipMalloc(&b, bytes));
+    PG_HIP(hipMemsetAsync(a, 1, bytes, s));
+    const dim3 grid(256 * 8), block(256);
+    for (int it = -1; it < iters; it++) {
+        if (it == 0) PG_HIP(hipEventRecord(e0, s));
+        if (lane_bytes == 16) launch(k_probe_copy16, grid, block, s, (const float4 *)a, (float4 *)b, (long long)(bytes / 16));
+        else launch(k_probe_copy8, grid, block, s, (const float2 *)a, (float2 *)b, (long long)(bytes / 8));
+    }
+    PG_HIP(hipEventRecord(e1, s));
+    PG_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    PG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gbps = (float)(2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9);  // read + write
+    (void)hipFree(a); (void)hipFree(b);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    return 0;
+}
+
 // stand-alone mixer launch (Mixer::processBlock), used by the Mixer step
 int run_mixer(hipStream_t s, const float2 *d_in, float2 *d_out, long long n, const OscBank &osc)
 {

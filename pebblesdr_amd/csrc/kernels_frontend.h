@@ -258,6 +258,16 @@ static __global__ __launch_bounds__(256) void k_save_tail(float2 *__restrict__ d
     b[-hist + j] = b[n - hist + j];
 }
 
+// Bandwidth probes for the roofline (bench.py): plain streaming copies with 16-byte and 8-byte lanes.
+static __global__ __launch_bounds__(256) void k_probe_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+static __global__ __launch_bounds__(256) void k_probe_copy8(const float2 *__restrict__ src, float2 *__restrict__ dst, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 // All history tails of a call in one launch: buf[c][-hist + j] = buf[c][n - hist + j], j < hist, for every buffer.
 // n may be shorter than hist (then part of the old history is kept, shifted), so a workgroup first reads every value
 // it will write.  grid (1, C, jobs), hist <= 256*32.

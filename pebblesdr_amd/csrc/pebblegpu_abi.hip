@@ -8,6 +8,7 @@ struct pebblegpu_receiver {
 };
 
 using pg::fail;
+namespace pg { int probe_copy(int lane_bytes, size_t bytes, int iters, float *gbps); }
 
 extern "C" {
 
@@ -66,6 +67,13 @@ int pebblegpu_device_synchronize(int device)
     if (int rc = need_device(device)) return rc;
     PG_HIP(hipDeviceSynchronize());
     return 0;
+}
+
+int pebblegpu_probe_copy_gbps(int device, int lane_bytes, size_t bytes, int iters, float *gbps)
+{
+    if (!gbps || iters <= 0 || bytes < 4096 || (lane_bytes != 8 && lane_bytes != 16)) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = need_device(device)) return rc;
+    return pg::probe_copy(lane_bytes, bytes & ~(size_t)4095, iters, gbps);
 }
 
 int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out)

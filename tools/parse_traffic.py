@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/pmc_workload.py into per-kernel HBM bytes.
+
+Correction per MI355X_MICROARCH.md (HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of
+a wide coalesced streaming read -- calibrated here on the known-size copy probes in the same pass (16-byte and
+8-byte lanes), and the read side of each kernel is scaled by the probe whose lane width matches its loads."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main(fetch_dir, write_dir, out):
+    fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    gib = float(1 << 30)
+
+    def first(acc, key):
+        for k, v in acc.items():
+            if key in k:
+                return sum(v) / len(v)
+        return None
+
+    cal = {}
+    for lanes, key in ((16, "k_probe_copy16"), (8, "k_probe_copy8")):
+        f, w = first(fe, key), first(wr, key)
+        cal[lanes] = {"fetch_KiB": f, "write_KiB": w, "read_scale": gib / (f * 1024.0), "write_scale": gib / (w * 1024.0)}
+    res = {"calibration": cal, "kernels": {}}
+    # loads: k_spectrum and k_wfm_mono/k_cascade use 8-byte lanes, k_mix_dec1 16-byte lanes; stores: spectrum 16-byte, rest 8-byte
+    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_cascade": (8, 8), "k_wfm_mono": (8, 8)}
+    for name, (lr, lw) in lanes.items():
+        f, w = first(fe, name), first(wr, name)
+        if f is None:
+            continue
+        rb = f * 1024.0 * cal[lr]["read_scale"]
+        wb = w * 1024.0 * cal[lw]["write_scale"]
+        res["kernels"][name] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "read_bytes": rb, "write_bytes": wb, "hbm_bytes": rb + wb}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
