@@ -114,8 +114,9 @@ int pebblegpu_set_mixer_freq(pebblegpu_receiver *rx, uint32_t channel, double fr
 /* Receiver::filterChanged (receiver.cpp:658-664): BandPassFilter::setBandPass -> CFastFIR::SetupParameters
  * (lo, hi, offset 0, demod rate) and, for AM channels, Demod_AM::setBandwidth(hi - lo). */
 int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_hz, double hi_hz);
-/* Receiver::demodModeChanged -> Demod::setDemodMode (receiver.cpp:640-655).  Narrow banks accept AM and
- * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM. */
+/* Receiver::demodModeChanged -> Demod::setDemodMode (receiver.cpp:640-655).  Narrow banks accept AM, SAM, FMN and
+ * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM (mono).  FMS (stereo + RDS) is a
+ * later row. */
 int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
 
 /* Batched device path.  d_iq: n_streams x n_samples float2 (stream-major, [stream][time]); n_samples must be

@@ -204,7 +204,8 @@ class Spectrum:
 
 
 class _FirS(C.Structure):
-    _fields_ = [("ntaps", C.c_int), ("state", C.c_int), ("coef", C.c_double * 150),
+    _fields_ = [("ntaps", C.c_int), ("state", C.c_int), ("fs", C.c_double), ("coef", C.c_double * 150),
+                ("icoef", C.c_double * 150), ("qcoef", C.c_double * 150),
                 ("zre", C.c_double * 75), ("zim", C.c_double * 75)]
 
 
@@ -221,6 +222,12 @@ class Fir:
 
     def taps(self):
         return np.array(self.s.coef[: self.s.ntaps])
+
+    def generate_hb(self, freq_offset):
+        lib().po_fir_generate_hb(C.byref(self.s), C.c_double(freq_offset))
+
+    def iq_taps(self):
+        return np.array(self.s.icoef[: self.s.ntaps]), np.array(self.s.qcoef[: self.s.ntaps])
 
     def process(self, x):
         x = _c128(x)
@@ -276,6 +283,52 @@ class DemodAM:
         x = _c128(x)
         out = np.empty_like(x)
         lib().po_demod_am_process(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
+        return out
+
+
+class _NfmS(C.Structure):
+    _fields_ = [("fs", C.c_double)] + [(n, C.c_float) for n in ("err_dc", "nco_freq", "nco_lo", "nco_hi", "phase", "alpha", "beta",
+                                                                "dc_alpha", "out_gain")] + [("lp", _FirS)]
+
+
+class DemodNFM:
+    """application/demod/demod_nfm.cpp processBlockNCO"""
+
+    def __init__(self, fs):
+        self.s = _NfmS()
+        lib().po_demod_nfm_init(C.byref(self.s), C.c_double(fs))
+
+    @property
+    def ntaps(self):
+        return self.s.lp.ntaps
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_demod_nfm_process(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
+        return out
+
+
+class _SamS(C.Structure):
+    _fields_ = [("fs", C.c_double)] + [(n, C.c_float) for n in ("lo", "hi", "freq", "phase", "alpha", "beta")] + \
+               [(n, C.c_double) for n in ("dc_re", "dc_re_last", "dc_im", "dc_im_last")] + [("bp", _FirS)]
+
+
+class DemodSAM:
+    """application/demod/demod_sam.cpp processBlock"""
+
+    def __init__(self, fs):
+        self.s = _SamS()
+        lib().po_demod_sam_init(C.byref(self.s), C.c_double(fs))
+
+    @property
+    def ntaps(self):
+        return self.s.bp.ntaps
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_demod_sam_process(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
         return out
 
 

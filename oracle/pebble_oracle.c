@@ -509,9 +509,22 @@ int po_fir_init_lp(po_fir *f, int ntaps, double scale, double astop, double fpas
         f->coef[n] = scale * c * po_izero(beta * sqrt(1 - (x * x))) / izb;
     }
     for (int n = 0; n < f->ntaps; n++) f->coef[n + f->ntaps] = f->coef[n];
+    for (int n = 0; n < f->ntaps * 2; n++) { f->icoef[n] = f->coef[n]; f->qcoef[n] = f->coef[n]; } /* fir.cpp:289-294 */
     for (int i = 0; i < f->ntaps; i++) { f->zre[i] = 0; f->zim[i] = 0; }
     f->state = 0;
+    f->fs = fs;
     return f->ntaps;
+}
+
+/* CFir::GenerateHBFilter, fir.cpp:454-468: heterodyne the low-pass prototype into an I/Q (Hilbert) band-pass pair */
+void po_fir_generate_hb(po_fir *f, double freq_offset)
+{
+    for (int n = 0; n < f->ntaps; n++) {
+        double a = (PO_TWOPI * freq_offset / f->fs) * ((double)n - ((double)(f->ntaps - 1) / 2.0));
+        f->icoef[n] = 2.0 * f->coef[n] * cos(a);
+        f->qcoef[n] = 2.0 * f->coef[n] * sin(a);
+    }
+    for (int n = 0; n < f->ntaps; n++) { f->icoef[n + f->ntaps] = f->icoef[n]; f->qcoef[n + f->ntaps] = f->qcoef[n]; }
 }
 
 /* CFir::ProcessFilter (complex), fir.cpp:106-132: circular delay line, summation in slot order */
@@ -520,9 +533,9 @@ void po_fir_process_cpx(po_fir *f, int n, const double *in, double *out)
     for (int i = 0; i < n; i++) {
         f->zre[f->state] = in[2 * i];
         f->zim[f->state] = in[2 * i + 1];
-        const double *h = f->coef + f->ntaps - f->state;
-        double ar = h[0] * f->zre[0], ai = h[0] * f->zim[0];
-        for (int j = 1; j < f->ntaps; j++) { ar += h[j] * f->zre[j]; ai += h[j] * f->zim[j]; }
+        const double *hi = f->icoef + f->ntaps - f->state, *hq = f->qcoef + f->ntaps - f->state;
+        double ar = hi[0] * f->zre[0], ai = hq[0] * f->zim[0];
+        for (int j = 1; j < f->ntaps; j++) { ar += hi[j] * f->zre[j]; ai += hq[j] * f->zim[j]; }
         if (--f->state < 0) f->state += f->ntaps;
         out[2 * i] = ar; out[2 * i + 1] = ai;
     }
@@ -598,6 +611,93 @@ void po_demod_am_process(po_demod_am *d, const double *in, double *out, int n) /
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * NFM demod (PLL) -- application/demod/demod_nfm.cpp.  parity unpinned: the reference offers no vector for it.
+ * ---------------------------------------------------------------------------------------------- */
+void po_demod_nfm_init(po_demod_nfm *d, double fs) /* ctor :24-37, init :44-66 */
+{
+    memset(d, 0, sizeof(*d));
+    d->fs = fs;
+    double norm = PO_TWOPI / fs;
+    d->nco_lo = (float)(-15000.0 * norm);                 /* FMPLL_RANGE */
+    d->nco_hi = (float)(15000.0 * norm);
+    d->alpha = (float)(2.0 * .707 * 3000.0 * norm);       /* FMPLL_ZETA, FMPLL_BW = VOICE_BANDWIDTH */
+    d->beta = (float)((double)(d->alpha * d->alpha) / (4.0 * .707 * .707)); /* float*float, then double divide */
+    d->out_gain = 1.0f;
+    d->dc_alpha = (float)(1.0 - exp(-1.0 / (fs * 0.001))); /* FMDC_ALPHA */
+    po_fir_init_lp(&d->lp, 0, 1.0, 50.0, 3000.0, 1.6 * 3000.0, fs);
+}
+void po_demod_nfm_process(po_demod_nfm *d, const double *in, double *out, int n) /* processBlockNCO :225-257 */
+{
+    for (int i = 0; i < n; i++) {
+        double nco_sin = (double)sinf(d->phase), nco_cos = (double)cosf(d->phase); /* sin(float) -> float overload */
+        double tr = nco_cos * in[2 * i] - nco_sin * in[2 * i + 1];
+        double ti = nco_cos * in[2 * i + 1] + nco_sin * in[2 * i];
+        double phzerror = -atan2(ti, tr);
+        d->nco_freq = (float)((double)d->nco_freq + ((double)d->beta * phzerror));
+        if (d->nco_freq > d->nco_hi) d->nco_freq = d->nco_hi;
+        else if (d->nco_freq < d->nco_lo) d->nco_freq = d->nco_lo;
+        d->phase = (float)((double)d->phase + ((double)d->nco_freq + (double)d->alpha * phzerror));
+        d->err_dc = (float)((1.0 - (double)d->dc_alpha) * (double)d->err_dc + (double)d->dc_alpha * (double)d->nco_freq);
+        float o = (d->nco_freq - d->err_dc) * d->out_gain; /* float arithmetic; CPX = real assigns imag 0 */
+        out[2 * i] = (double)o;
+        out[2 * i + 1] = 0.0;
+    }
+    d->phase = (float)fmod((double)d->phase, PO_TWOPI);
+    po_fir_process_cpx(&d->lp, n, out, out);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SAM demod (PLL) -- application/demod/demod_sam.cpp.  parity unpinned: the reference offers no vector for it.
+ * ---------------------------------------------------------------------------------------------- */
+void po_demod_sam_init(po_demod_sam *d, double fs) /* ctor :5-32; sampleRate is quint32 there */
+{
+    memset(d, 0, sizeof(*d));
+    d->fs = fs;
+    int bw = 100, lim = 1000;
+    float zeta = 0.707f;
+    d->alpha = (float)(2.0 * zeta * bw * PO_TWOPI / fs);
+    d->beta = (float)((double)(d->alpha * d->alpha) / (4.0 * zeta * zeta));
+    d->lo = (float)(-lim * PO_TWOPI / fs);
+    d->hi = (float)(lim * PO_TWOPI / fs);
+    po_fir_init_lp(&d->bp, 0, 1.0, 40.0, 4500, 5500, fs);
+    po_fir_generate_hb(&d->bp, 5000.0);
+}
+static double po_phase_cpx(double re, double im) /* CpxUtil::phaseCpx, cpx.cpp:5-21 */
+{
+    double t = atan(im / ((re == 0) ? 1e-200 : re));
+    if (re < 0 && im < 0) t -= 3.14159265358979323846;
+    else if (re < 0 && im >= 0) t += 3.14159265358979323846;
+    return t;
+}
+void po_demod_sam_process(po_demod_sam *d, const double *in, double *out, int n) /* :41-112 */
+{
+    for (int i = 0; i < n; i++) {
+        double sr = in[2 * i], si = in[2 * i + 1];
+        double zr = (double)cosf(d->phase), zi = (double)sinf(d->phase);
+        double pr = zr * sr - zi * si, pi = zr * si + zi * sr; /* z * sig */
+        float diff = (float)(sqrt(sr * sr + si * si) * po_phase_cpx(pr, pi));
+        d->freq = d->freq + d->beta * diff; /* float arithmetic */
+        if (d->freq < d->lo) d->freq = d->lo;
+        if (d->freq > d->hi) d->freq = d->hi;
+        d->phase = d->phase + (d->freq + d->alpha * diff);
+        while ((double)d->phase >= PO_TWOPI) d->phase = (float)((double)d->phase - PO_TWOPI);
+        while (d->phase < 0) d->phase = (float)((double)d->phase + PO_TWOPI);
+        d->dc_re = (0.9999f * d->dc_re_last) + pr;
+        d->dc_im = (0.9999f * d->dc_im_last) + pi;
+        out[2 * i] = d->dc_re - d->dc_re_last;
+        out[2 * i + 1] = d->dc_im - d->dc_im_last;
+        d->dc_re_last = d->dc_re;
+        d->dc_im_last = d->dc_im;
+    }
+    po_fir_process_cpx(&d->bp, n, out, out);
+    for (int i = 0; i < n; i++) {
+        double tr = out[2 * i], ti = out[2 * i + 1];
+        out[2 * i + 1] = tr - ti; /* upper sideband -> right */
+        out[2 * i] = tr + ti;     /* lower sideband -> left */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * WFM mono demod -- application/demod/demod_wfm.cpp
  * ---------------------------------------------------------------------------------------------- */
 void po_demod_wfm_init(po_demod_wfm *d, double fs) /* init()+setSampleRate(), demod_wfm.cpp:100-196 */
@@ -642,6 +742,8 @@ struct po_receiver {
     po_spectrum *spec;
     po_fastfir *bp;
     po_demod_am am;
+    po_demod_nfm nfm;
+    po_demod_sam sam;
     po_demod_wfm wfm;
     double *mixed, *working, *samplebuf, *bpout, *demodout;
     uint32_t samplebuf_len;
@@ -659,6 +761,8 @@ po_receiver *po_receiver_new(uint32_t fs, uint32_t n, uint32_t spectrum_bins, ui
     if (spectrum_bins) r->spec = po_spectrum_new(spectrum_bins, n, 0, 0); /* :221, signalspectrum.cpp:58 */
     r->bp = po_fastfir_new(fastfir_fft ? fastfir_fft : 2048, fastfir_taps ? fastfir_taps : 1025); /* :261 */
     po_demod_am_init(&r->am, (double)r->demod_rate);                     /* :228, demod.cpp:62 */
+    po_demod_sam_init(&r->sam, (double)r->demod_rate);                   /* demod.cpp:63 */
+    po_demod_nfm_init(&r->nfm, (double)r->demod_rate);                   /* demod.cpp:64 */
     po_demod_wfm_init(&r->wfm, (double)r->wfm_rate);                     /* demod.cpp:65 */
     r->mixed = (double *)calloc((size_t)n * 2, sizeof(double));
     r->working = (double *)calloc((size_t)n * 2, sizeof(double));
@@ -726,6 +830,8 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     if (r->mode == PO_NONE) { memset(audio, 0, (size_t)nb * 2 * sizeof(double)); return (uint32_t)nb; } /* :968-971 */
     /* :987 demod (AGC/ANF identity, see header) */
     if (r->mode == PO_AM) po_demod_am_process(&r->am, r->bpout, audio, nb);
+    else if (r->mode == PO_SAM) po_demod_sam_process(&r->sam, r->bpout, audio, nb);
+    else if (r->mode == PO_FMN) po_demod_nfm_process(&r->nfm, r->bpout, audio, nb);
     else memcpy(audio, r->bpout, (size_t)nb * 2 * sizeof(double)); /* SSB/CW/DIG/DSB pass-through, demod.cpp:127-138 */
     return (uint32_t)nb;
 }

@@ -81,10 +81,13 @@ int po_spectrum_process(po_spectrum *s, const double *in, uint32_t n, double *ou
 /* ---- CFir: pebblelib/fir.cpp:106-132, 246-337, 494-512 ---- */
 typedef struct {
     int ntaps, state;
-    double coef[2 * 75];
+    double fs;
+    double coef[2 * 75];              /* m_Coef (prototype low-pass) */
+    double icoef[2 * 75], qcoef[2 * 75]; /* m_ICoef / m_QCoef: what the complex ProcessFilter uses */
     double zre[75], zim[75];
 } po_fir;
 int po_fir_init_lp(po_fir *f, int ntaps, double scale, double astop, double fpass, double fstop, double fs);
+void po_fir_generate_hb(po_fir *f, double freq_offset);                  /* CFir::GenerateHBFilter, fir.cpp:454-468 */
 void po_fir_process_cpx(po_fir *f, int n, const double *in, double *out); /* in may == out */
 
 /* ---- CIir: pebblelib/iir.cpp:88-207 ---- */
@@ -100,6 +103,26 @@ typedef struct { double fs, dc, dc_last; po_fir lp; } po_demod_am;
 void po_demod_am_init(po_demod_am *d, double fs);
 void po_demod_am_set_bandwidth(po_demod_am *d, double bw);
 void po_demod_am_process(po_demod_am *d, const double *in, double *out, int n);
+
+/* ---- Demod_NFM::processBlockNCO: application/demod/demod_nfm.cpp:44-66,225-257.  State members are `float` in the
+ * reference (demod_nfm.h:27-40) and sin/cos of a float argument resolve to the float overloads in C++ ---- */
+typedef struct {
+    double fs;
+    float err_dc, nco_freq, nco_lo, nco_hi, phase, alpha, beta, dc_alpha, out_gain;
+    po_fir lp;
+} po_demod_nfm;
+void po_demod_nfm_init(po_demod_nfm *d, double fs);
+void po_demod_nfm_process(po_demod_nfm *d, const double *in, double *out, int n);
+
+/* ---- Demod_SAM::processBlock / pll: application/demod/demod_sam.cpp:5-112 (float PLL state, demod_sam.h:19-25) ---- */
+typedef struct {
+    double fs;
+    float lo, hi, freq, phase, alpha, beta;
+    double dc_re, dc_re_last, dc_im, dc_im_last;
+    po_fir bp;
+} po_demod_sam;
+void po_demod_sam_init(po_demod_sam *d, double fs);
+void po_demod_sam_process(po_demod_sam *d, const double *in, double *out, int n);
 
 /* ---- Demod_WFM::processDataMono: application/demod/demod_wfm.cpp:154-232, 451-485 ---- */
 typedef struct {

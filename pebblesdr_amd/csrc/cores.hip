@@ -444,10 +444,93 @@ int AmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out
     launch(k_iir_scan<2, 1>, dim3(1, na), dim3(64), s, in, in_pitch, tmp.data(), tmp.pitch, n, scan, (const double *)d_state, d_state,
            (int)nsub, -1, (const int *)d_list);
     launch(k_fir_dec, dim3(cdiv(n, 256), na), dim3(256), s, (const float2 *)tmp.data(), tmp.pitch, out, out_pitch, n, 1,
-           (const float *)d_taps, (int)kMaxTaps, (const int *)d_ntaps, 0, 1.0f, (const int *)d_list);
+           (const float *)d_taps, (const float *)nullptr, (int)kMaxTaps, (const int *)d_ntaps, 0, 1.0f, 0, (const int *)d_list);
     launch(k_save_tail, dim3(cdiv(tmp.hist, 256), na), dim3(256), s, tmp.data(), tmp.pitch, n, tmp.hist, (const int *)d_list);
     PG_HIP(hipGetLastError());
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PllCore: Demod_NFM (mode 0) or Demod_SAM (mode 1) for the listed channels
+// ------------------------------------------------------------------------------------------------
+int PllCore::init(uint32_t channels, double demod_rate, long long max_n, int which)
+{
+    C = channels;
+    rate = demod_rate;
+    mode = which;
+    memset(&pp, 0, sizeof(pp));
+    pp.mode = mode;
+    std::vector<double> h;
+    std::vector<float> hi(kMaxTaps, 0.f), hq(kMaxTaps, 0.f);
+    if (mode == 0) {  // Demod_NFM::init, demod_nfm.cpp:44-66 (float members, demod_nfm.h:27-40)
+        const double norm = design::kTwoPi / rate;
+        pp.lo = (float)(-15000.0 * norm);  // FMPLL_RANGE
+        pp.hi = (float)(15000.0 * norm);
+        pp.alpha = (float)(2.0 * .707 * 3000.0 * norm);  // FMPLL_ZETA, FMPLL_BW
+        pp.beta = (float)((double)(pp.alpha * pp.alpha) / (4.0 * .707 * .707));
+        pp.out_gain = 1.0f;
+        pp.dc_alpha = (float)(1.0 - std::exp(-1.0 / (rate * 0.001)));  // FMDC_ALPHA
+        h = design::fir_lowpass(0, 1.0, 50.0, 3000.0, 1.6 * 3000.0, rate);
+        for (size_t i = 0; i < h.size(); i++) hi[i] = hq[i] = (float)h[i];
+    } else {          // Demod_SAM ctor, demod_sam.cpp:5-32
+        const float zeta = 0.707f;
+        pp.alpha = (float)(2.0 * zeta * 100 * design::kTwoPi / rate);
+        pp.beta = (float)((double)(pp.alpha * pp.alpha) / (4.0 * zeta * zeta));
+        pp.lo = (float)(-1000 * design::kTwoPi / rate);
+        pp.hi = (float)(1000 * design::kTwoPi / rate);
+        h = design::fir_lowpass(0, 1.0, 40.0, 4500, 5500, rate);
+        const int nt = (int)h.size();
+        for (int n = 0; n < nt; n++) {  // GenerateHBFilter(5000.0), fir.cpp:454-468
+            const double a = (design::kTwoPi * 5000.0 / rate) * ((double)n - ((double)(nt - 1) / 2.0));
+            hi[n] = (float)(2.0 * h[n] * std::cos(a));
+            hq[n] = (float)(2.0 * h[n] * std::sin(a));
+        }
+    }
+    ntaps = (int)h.size();
+    // k_fir_dec computes sum_p x[i-(T-1)+p] h[p]; CFir computes sum_k coef[k] x[i-k]: store the taps reversed
+    std::vector<float> ri(kMaxTaps, 0.f), rq(kMaxTaps, 0.f);
+    for (int p = 0; p < ntaps; p++) { ri[p] = hi[ntaps - 1 - p]; rq[p] = hq[ntaps - 1 - p]; }
+    PG_HIP(hipMalloc((void **)&d_taps_i, sizeof(float) * kMaxTaps));
+    PG_HIP(hipMalloc((void **)&d_taps_q, sizeof(float) * kMaxTaps));
+    PG_HIP(hipMemcpy(d_taps_i, ri.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
+    PG_HIP(hipMemcpy(d_taps_q, rq.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
+    if (int rc = tmp.alloc((int)C, kMaxTaps, max_n)) return rc;
+    PG_HIP(hipMalloc((void **)&d_state, sizeof(PllState) * C));
+    PG_HIP(hipMemset(d_state, 0, sizeof(PllState) * C));
+    PG_HIP(hipMalloc((void **)&d_list, sizeof(int) * C));
+    return 0;
+}
+void PllCore::release()
+{
+    tmp.release();
+    void *p[] = {d_taps_i, d_taps_q, d_state, d_list};
+    for (void *q : p) if (q) (void)hipFree(q);
+    d_taps_i = d_taps_q = nullptr;
+    d_state = nullptr;
+    d_list = nullptr;
+}
+int PllCore::set_list(hipStream_t s, const std::vector<int> &channels)
+{
+    list = channels;
+    if (!list.empty()) {
+        PG_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, s));
+        PG_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+int PllCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
+{
+    if (list.empty()) return 0;
+    if (n > tmp.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+    const unsigned nl = (unsigned)list.size();
+    launch(k_pll_demod, dim3(cdiv(nl, 64)), dim3(64), s, in, in_pitch, tmp.data(), tmp.pitch, n, pp, d_state, (const int *)d_list,
+           (int)nl);
+    launch(k_fir_dec, dim3(cdiv(n, 256), nl), dim3(256), s, (const float2 *)tmp.data(), tmp.pitch, out, out_pitch, n, 1, (const float *)d_taps_i,
+           (const float *)d_taps_q, 0, (const int *)nullptr, ntaps, 1.0f, mode == 1 ? 1 : 0, (const int *)d_list);
+    std::vector<TailJob> jobs;
+    // listed channels only would need a list-aware tail kernel; refreshing every row is harmless (idle rows keep zeros)
+    jobs.push_back(TailJob{tmp.data(), tmp.pitch, n, tmp.hist, 0});
+    return run_save_tails(s, jobs, C);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -535,8 +618,8 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
     else
         launch(k_copy, dim3(cdiv(n, 256), C), dim3(256), s, in, in_pitch, a.data(), a.pitch, n);
     launch(k_discrim, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)a.data(), a.pitch, b.data(), b.pitch, n, 0.25f);  // FMDEMOD_GAIN
-    launch(k_fir_dec, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)b.data(), b.pitch, c.data(), c.pitch, n, 1, (const float *)d_taps, 0,
-           (const int *)nullptr, ntaps, 1.0f, (const int *)nullptr);
+    launch(k_fir_dec, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)b.data(), b.pitch, c.data(), c.pitch, n, 1, (const float *)d_taps,
+           (const float *)nullptr, 0, (const int *)nullptr, ntaps, 1.0f, 0, (const int *)nullptr);
     launch(k_iir_scan<1, 2>, dim3(1, C), dim3(64), s, (const float2 *)c.data(), c.pitch, out, out_pitch, n, dn, (const double *)d_dn_state[0],
            d_dn_state[0], (int)nsub, -1, (const int *)nullptr);
     PG_HIP(hipGetLastError());

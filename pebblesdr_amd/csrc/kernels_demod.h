@@ -292,6 +292,63 @@ static __global__ __launch_bounds__(256) void k_wfm_mono(const float2 *__restric
     }
 }
 
+// The PLL demodulators -- Demod_NFM::processBlockNCO (application/demod/demod_nfm.cpp:225-257) and Demod_SAM::pll /
+// processBlock (demod_sam.cpp:41-101) -- are NON-linear feedback loops: serial in time, parallel only across channels.
+// One lane per channel walks the call; the loop state is `float` exactly as the reference declares it
+// (demod_nfm.h:27-40, demod_sam.h:19-25), trigonometry of the float phase uses the float functions (what sin(float)
+// resolves to in C++), everything else is double as written.  Output goes to a buffer with FIR head-room; the
+// CFir that follows is k_fir_dec.
+static __global__ __launch_bounds__(64) void k_pll_demod(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ out,
+                                                         long long out_pitch, long long n, PllParams pp, PllState *__restrict__ st,
+                                                         const int *__restrict__ chan_list, int nlist)
+{
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nlist) return;
+    const int c = chan_list ? chan_list[li] : li;
+    const float2 *x = in + (long long)c * in_pitch;
+    float2 *y = out + (long long)c * out_pitch;
+    PllState s = st[c];
+    const double kTwoPi = 6.28318530717958647692528676656, kPiD = 3.14159265358979323846;
+    if (pp.mode == 0) {
+        for (long long i = 0; i < n; i++) {
+            const double nco_sin = (double)sinf(s.phase), nco_cos = (double)cosf(s.phase);
+            const float2 v = x[i];
+            const double tr = nco_cos * (double)v.x - nco_sin * (double)v.y;
+            const double ti = nco_cos * (double)v.y + nco_sin * (double)v.x;
+            const double phzerror = -atan2(ti, tr);
+            s.freq = (float)((double)s.freq + ((double)pp.beta * phzerror));
+            if (s.freq > pp.hi) s.freq = pp.hi;
+            else if (s.freq < pp.lo) s.freq = pp.lo;
+            s.phase = (float)((double)s.phase + ((double)s.freq + (double)pp.alpha * phzerror));
+            s.err_dc = (float)((1.0 - (double)pp.dc_alpha) * (double)s.err_dc + (double)pp.dc_alpha * (double)s.freq);
+            y[i] = make_float2(__fmul_rn(__fsub_rn(s.freq, s.err_dc), pp.out_gain), 0.f);  // float arithmetic; CPX = real: imag 0
+        }
+        s.phase = (float)fmod((double)s.phase, kTwoPi);  // "keep radian counter bounded", once per block
+    } else {
+        for (long long i = 0; i < n; i++) {
+            const float2 v = x[i];
+            const double sr = (double)v.x, si = (double)v.y;
+            const double zr = (double)cosf(s.phase), zi = (double)sinf(s.phase);
+            const double pr = zr * sr - zi * si, pi = zr * si + zi * sr;
+            double ph = atan(pi / ((pr == 0) ? 1e-200 : pr));  // CpxUtil::phaseCpx, cpx.cpp:5-21
+            if (pr < 0 && pi < 0) ph -= kPiD;
+            else if (pr < 0 && pi >= 0) ph += kPiD;
+            const float diff = (float)(sqrt(sr * sr + si * si) * ph);
+            s.freq = __fadd_rn(s.freq, __fmul_rn(pp.beta, diff));  // float arithmetic, no FMA contraction (as an x86-64 build)
+            if (s.freq < pp.lo) s.freq = pp.lo;
+            if (s.freq > pp.hi) s.freq = pp.hi;
+            s.phase = __fadd_rn(s.phase, __fadd_rn(s.freq, __fmul_rn(pp.alpha, diff)));
+            while ((double)s.phase >= kTwoPi) s.phase = (float)((double)s.phase - kTwoPi);
+            while (s.phase < 0) s.phase = (float)((double)s.phase + kTwoPi);
+            const double dre = ((double)0.9999f * s.dc_re_last) + pr, dim = ((double)0.9999f * s.dc_im_last) + pi;
+            y[i] = make_float2((float)(dre - s.dc_re_last), (float)(dim - s.dc_im_last));
+            s.dc_re_last = dre;
+            s.dc_im_last = dim;
+        }
+    }
+    st[c] = s;
+}
+
 // FM discriminator, demod_wfm.cpp:214-220: out = gain * atan2(I1*Q0 - I0*Q1, I1*I0 + Q1*Q0), written to
 // both components.  in[-1] is the previous call's last sample (head-room 1).  grid (ceil(n/256), C).
 static __global__ __launch_bounds__(256) void k_discrim(const float2 *__restrict__ in, long long in_pitch,

@@ -218,32 +218,41 @@ static __global__ __launch_bounds__(64) void k_mix_tail(const float2 *__restrict
     hist[(long long)c * hist_pitch + j] = m;
 }
 
-// Generic real-tap FIR on complex data with decimation: later halfband stages (stride 2^k) and the
-// CFir post-demod filters (stride 1).  `in` points at the data start; in[-(T-1)..-1] is history.
-//   y[c][o] = gain * sum_p in[c][o*S + p - (T-1)] * h_c[p]
-// taps: either one set for all channels (taps_pitch == 0) or per channel, in device memory.
-// grid (ceil(n_out/256), C).
+// Generic real-tap FIR on complex data with decimation: the CFir post-demod filters (stride 1) and any stand-alone
+// strided FIR.  `in` points at the data start; in[-(T-1)..-1] is history.
+//   y[c][o].re = gain * sum_p in[c][o*S + p - (T-1)].re * hI_c[p],   y.im likewise with hQ (CFir::ProcessFilter complex,
+//   pebblelib/fir.cpp:106-132: separate I and Q coefficient sets; equal except after GenerateHBFilter)
+// taps: one set for all channels (taps_pitch == 0) or per channel, in device memory; taps_q == nullptr => hQ = hI.
+// sideband_mix: out = (re + im, re - im), the last loop of Demod_SAM::processBlock (demod_sam.cpp:103-110).
+// grid (ceil(n_out/256), C or listed channels).
 static __global__ __launch_bounds__(256) void k_fir_dec(const float2 *__restrict__ in, long long in_pitch,
                                                   float2 *__restrict__ out, long long out_pitch, long long n_out,
-                                                  int stride, const float *__restrict__ taps, int taps_pitch,
-                                                  const int *__restrict__ ntaps_per_chan, int ntaps_all, float gain,
-                                                  const int *__restrict__ chan_list)
+                                                  int stride, const float *__restrict__ taps, const float *__restrict__ taps_q,
+                                                  int taps_pitch, const int *__restrict__ ntaps_per_chan, int ntaps_all,
+                                                  float gain, int sideband_mix, const int *__restrict__ chan_list)
 {
+    __shared__ float hi[kMaxTaps], hq[kMaxTaps];
     const int c = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    const int T = ntaps_per_chan ? ntaps_per_chan[c] : ntaps_all;
+    if (threadIdx.x < kMaxTaps) {
+        const int p = threadIdx.x;
+        const float a = p < T ? taps[(long long)c * taps_pitch + p] : 0.f;
+        hi[p] = a;
+        hq[p] = (taps_q && p < T) ? taps_q[(long long)c * taps_pitch + p] : a;
+    }
+    __syncthreads();
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= n_out) return;
-    const int T = ntaps_per_chan ? ntaps_per_chan[c] : ntaps_all;
-    const float *h = taps + (long long)c * taps_pitch;
     const float2 *x = in + (long long)c * in_pitch + o * stride - (T - 1);
     float2 acc = make_float2(0.f, 0.f);
     for (int p = 0; p < T; p++) {
-        const float hp = h[p];
-        if (hp == 0.f) continue;
         const float2 v = x[p];
-        acc.x = fmaf(v.x, hp, acc.x);
-        acc.y = fmaf(v.y, hp, acc.y);
+        acc.x = fmaf(v.x, hi[p], acc.x);
+        acc.y = fmaf(v.y, hq[p], acc.y);
     }
-    out[(long long)c * out_pitch + o] = cscale(acc, gain);
+    acc = cscale(acc, gain);
+    if (sideband_mix) acc = make_float2(acc.x + acc.y, acc.x - acc.y);
+    out[(long long)c * out_pitch + o] = acc;
 }
 
 // Copy the last `hist` samples of each channel's data into its head-room: buf[c][-hist + j] = buf[c][n - hist + j].

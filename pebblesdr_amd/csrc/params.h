@@ -52,6 +52,18 @@ struct ScanSection {
 };
 template <int NSEC> struct ScanParams { ScanSection sec[NSEC]; };
 
+// PLL demodulators (k_pll_demod): loop constants and per-channel state, floats as the reference declares them
+struct PllParams {
+    int mode;                 // 0: NFM, 1: SAM
+    float lo, hi, alpha, beta;
+    float dc_alpha, out_gain; // NFM only
+    int pad_;
+};
+struct PllState {             // per channel
+    float freq, phase, err_dc, pad_;
+    double dc_re_last, dc_im_last;  // SAM DC removal (doubles, demod_sam.h:27-31)
+};
+
 // history-tail refresh jobs: buf[c][-hist + j] = buf[c][n - hist + j] for every channel c (one launch for all buffers)
 struct TailJob {
     float2 *data;

@@ -110,6 +110,23 @@ struct AmCore {
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
 };
 
+// ---- Demod_NFM / Demod_SAM (PLL demodulators) ----
+struct PllCore {
+    uint32_t C = 0;
+    double rate = 0;
+    int mode = 0, ntaps = 0;        // 0 NFM, 1 SAM
+    PllParams pp;
+    HistBuf tmp;                    // PLL output, head-room for the CFir
+    float *d_taps_i = nullptr, *d_taps_q = nullptr;
+    PllState *d_state = nullptr;
+    int *d_list = nullptr;
+    std::vector<int> list;
+    int init(uint32_t channels, double demod_rate, long long max_n, int which);
+    void release();
+    int set_list(hipStream_t s, const std::vector<int> &channels);
+    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+};
+
 // ---- Demod_WFM mono ----
 struct WfmCore {
     uint32_t C = 0;
@@ -187,10 +204,12 @@ private:
     hipStream_t stream_ = nullptr;
     std::vector<ChanCtl> ctl_;
     bool am_list_dirty_ = true;
+    long long pll_cap_ = 0;
     OscBank osc_;
     DecimCore dec_;
     FastFirCore ff_;
     AmCore am_;
+    PllCore nfm_, sam_;
     WfmCore wfmc_;
     SpectrumCore spec_;
     float2 *d_stage_in_ = nullptr;

@@ -52,6 +52,8 @@ int Receiver::create(const pebblegpu_config *cfg)
     if (!wfm) {
         if (int rc = ff_.init(C, ff_n, ff_taps)) return rc;
         if (int rc = am_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_AM(m_inputSampleRate), demod.cpp:62
+        // Demod_SAM / Demod_NFM objects also exist in every Receiver (demod.cpp:63-64); their buffers are allocated on first use
+        pll_cap_ = nd_max;
     } else {
         if (int rc = wfmc_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_WFM(m_inputWfmSampleRate), demod.cpp:65
     }
@@ -67,7 +69,7 @@ Receiver::~Receiver()
 {
     (void)hipSetDevice(device);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    osc_.release(); dec_.release(); ff_.release(); am_.release(); wfmc_.release(); spec_.release();
+    osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
     audio.release();
     if (d_spec) (void)hipFree(d_spec);
     if (d_stage_in_) (void)hipFree(d_stage_in_);
@@ -89,9 +91,8 @@ int Receiver::set_mode(uint32_t ch, int mode)
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     if (wfm) {
         if (mode != PEBBLEGPU_DM_FMM) return fail(PEBBLEGPU_E_UNSUPPORTED, "a WFM bank demodulates FMM (mono) only");
-    } else if (mode == PEBBLEGPU_DM_SAM || mode == PEBBLEGPU_DM_FMN || mode == PEBBLEGPU_DM_FMM || mode == PEBBLEGPU_DM_FMS ||
-               mode < 0 || mode > PEBBLEGPU_DM_NONE) {
-        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d is not built in a narrow bank (PLL demods are a later row)", mode);
+    } else if (mode == PEBBLEGPU_DM_FMM || mode == PEBBLEGPU_DM_FMS || mode < 0 || mode > PEBBLEGPU_DM_NONE) {
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d is not available in a narrow bank (WFM needs a wfm bank; stereo is a later row)", mode);
     }
     std::lock_guard<std::mutex> g(mu_);
     if (ctl_[ch].mode != mode) am_list_dirty_ = true;
@@ -138,9 +139,17 @@ int Receiver::apply_controls()
         }
     }
     if (am_list_dirty_) {
-        std::vector<int> l;
-        for (uint32_t ch = 0; ch < C; ch++) if (ctl_[ch].mode == PEBBLEGPU_DM_AM) l.push_back((int)ch);
+        std::vector<int> l, ls, ln;
+        for (uint32_t ch = 0; ch < C; ch++) {
+            if (ctl_[ch].mode == PEBBLEGPU_DM_AM) l.push_back((int)ch);
+            else if (ctl_[ch].mode == PEBBLEGPU_DM_SAM) ls.push_back((int)ch);
+            else if (ctl_[ch].mode == PEBBLEGPU_DM_FMN) ln.push_back((int)ch);
+        }
         if (int rc = am_.set_list(stream_, l)) return rc;
+        if (!ls.empty() && sam_.C == 0) { if (int rc = sam_.init(C, (double)demod_rate_int, pll_cap_, 1)) return rc; }
+        if (!ln.empty() && nfm_.C == 0) { if (int rc = nfm_.init(C, (double)demod_rate_int, pll_cap_, 0)) return rc; }
+        if (sam_.C) { if (int rc = sam_.set_list(stream_, ls)) return rc; }
+        if (nfm_.C) { if (int rc = nfm_.set_list(stream_, ln)) return rc; }
         am_list_dirty_ = false;
     }
     return 0;
@@ -179,6 +188,8 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipEventRecord(ev[4], stream_));
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
         if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
+        if (sam_.C) { if (int rc = sam_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
+        if (nfm_.C) { if (int rc = nfm_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
     } else {
         PG_HIP(hipEventRecord(ev[4], stream_));
         if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896

@@ -73,6 +73,7 @@ struct pebblegpu_demod : pg::StepBase {
     int mode = PEBBLEGPU_DM_AM;
     uint32_t cap = 0;
     pg::AmCore am;
+    pg::PllCore nfm, sam;
     pg::WfmCore wfm;
     float2 *d_in = nullptr, *d_out = nullptr;
 };
@@ -297,6 +298,12 @@ int pebblegpu_demod_create(int device, uint32_t sample_rate, uint32_t wfm_sample
         rc = d->am.set_bandwidth(d->stream, 0, 16000);  // Demod_AM ctor, demod_am.cpp:9
         if (!rc) rc = d->am.set_list(d->stream, std::vector<int>(1, 0));
     }
+    if (!rc && sample_rate) rc = d->sam.init(1, (double)sample_rate, buffer_size, 1);   // Demod_SAM, demod.cpp:63
+    if (!rc && sample_rate) rc = d->nfm.init(1, (double)sample_rate, buffer_size, 0);   // Demod_NFM, demod.cpp:64
+    if (!rc && sample_rate) {
+        rc = d->sam.set_list(d->stream, std::vector<int>(1, 0));
+        if (!rc) rc = d->nfm.set_list(d->stream, std::vector<int>(1, 0));
+    }
     if (!rc && wfm_sample_rate) rc = d->wfm.init(1, (double)wfm_sample_rate, buffer_size);
     if (!rc && hipMalloc((void **)&d->d_in, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
     if (!rc && hipMalloc((void **)&d->d_out, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
@@ -310,6 +317,8 @@ int pebblegpu_demod_destroy(pebblegpu_demod *d)
     if (!d) return 0;
     d->close_stream();
     d->am.release();
+    d->nfm.release();
+    d->sam.release();
     d->wfm.release();
     if (d->d_in) (void)hipFree(d->d_in);
     if (d->d_out) (void)hipFree(d->d_out);
@@ -320,9 +329,8 @@ int pebblegpu_demod_set_mode(pebblegpu_demod *d, int mode)
 {
     if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
     if (mode < 0 || mode > PEBBLEGPU_DM_NONE) return fail(PEBBLEGPU_E_INVALID, "bad mode %d", mode);
-    if (mode == PEBBLEGPU_DM_SAM || mode == PEBBLEGPU_DM_FMN || mode == PEBBLEGPU_DM_FMS)
-        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d (PLL / stereo) is a later row", mode);
-    if (mode == PEBBLEGPU_DM_AM && d->am.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a narrow sample rate");
+    if (mode == PEBBLEGPU_DM_FMS) return fail(PEBBLEGPU_E_UNSUPPORTED, "WFM stereo / RDS is a later row (SURVEY 8f-4)");
+    if ((mode == PEBBLEGPU_DM_AM || mode == PEBBLEGPU_DM_SAM || mode == PEBBLEGPU_DM_FMN) && d->am.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a narrow sample rate");
     if (mode == PEBBLEGPU_DM_FMM && d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
     d->mode = mode;
     return 0;
@@ -337,12 +345,17 @@ int pebblegpu_demod_set_bandwidth(pebblegpu_demod *d, double bw)
 int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const double **out)
 {
     if (!d || !in || !out || n <= 0) return fail(PEBBLEGPU_E_INVALID, "bad argument");
-    if (d->mode != PEBBLEGPU_DM_AM && d->mode != PEBBLEGPU_DM_FMM) { *out = in; return 0; }  // demod.cpp:127-138
+    if (d->mode != PEBBLEGPU_DM_AM && d->mode != PEBBLEGPU_DM_FMM && d->mode != PEBBLEGPU_DM_SAM && d->mode != PEBBLEGPU_DM_FMN) {
+        *out = in;  // demod.cpp:127-138
+        return 0;
+    }
     if ((uint32_t)n > d->cap) return fail(PEBBLEGPU_E_SIZE, "%d samples exceed bufferSize %u", n, d->cap);
     PG_HIP(hipSetDevice(d->device));
     if (int rc = d->up(d->d_in, in, (size_t)n)) return rc;
     int rc;
     if (d->mode == PEBBLEGPU_DM_AM) rc = d->am.run(d->stream, d->d_in, n, d->d_out, n, n);
+    else if (d->mode == PEBBLEGPU_DM_SAM) rc = d->sam.run(d->stream, d->d_in, n, d->d_out, n, n);
+    else if (d->mode == PEBBLEGPU_DM_FMN) rc = d->nfm.run(d->stream, d->d_in, n, d->d_out, n, n);
     else {
         rc = d->wfm.run(d->stream, d->d_in, n, d->d_out, n, n);
         if (!rc) {

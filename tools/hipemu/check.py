@@ -110,6 +110,19 @@ def case_demod():
         off = [0, n, 2 * n, 5 * n][k]
         r = ref.process(fm[off:off + ln]); g = d.processBlock(fm[off:off + ln])
         ok &= report("WFM demod call %d (n=%d)" % (k, ln), rel_rms(g, r), 1e-5)
+    # PLL demods
+    t = np.arange(6 * n) / 64000.0
+    fm = 0.3 * np.exp(1j * 3.0 * np.sin(2 * np.pi * 1000 * t)) + lcg_noise(6 * n, 7, 1e-3)
+    ref = O.DemodNFM(64000); d = St.Demod(64000, 256000, 2 * n, lib=L); d.setDemodMode(B.DM_FMN)
+    for k, (off, ln) in enumerate(((0, n), (n, n), (2 * n, 2 * n), (4 * n, 1000))):
+        r = ref.process(fm[off:off + ln]); g = d.processBlock(fm[off:off + ln])
+        ok &= report("NFM demod call %d" % k, rel_rms(g, r), 1e-5)
+    am = (0.3 * (1 + 0.5 * np.cos(2 * np.pi * 800 * t))) * np.exp(2j * np.pi * 30 * t) + lcg_noise(6 * n, 8, 1e-3)
+    ref = O.DemodSAM(64000); d = St.Demod(64000, 256000, 2 * n, lib=L); d.setDemodMode(B.DM_SAM)
+    for k, (off, ln) in enumerate(((0, n), (n, n), (2 * n, 2 * n), (4 * n, 1000))):
+        r = ref.process(am[off:off + ln]); g = d.processBlock(am[off:off + ln])
+        ok &= report("SAM demod call %d in-phase path" % k, rel_rms((g.real + g.imag) / 2, (r.real + r.imag) / 2), 1e-5)
+        ok &= report("SAM demod call %d quadrature path (chaotic in the reference)" % k, rel_rms((g.real - g.imag) / 2, (r.real - r.imag) / 2), 5e-2)
     return ok
 
 

@@ -208,6 +208,9 @@ static inline void sincospi(double x, double *s, double *c)
     *c = cos(a);
 }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 
 // ---- host runtime subset ----
