@@ -65,7 +65,18 @@ int pebblegpu_device_synchronize(int device);
 /* Streaming-copy probe (read + write GB/s of a plain device copy with 16- or 8-byte lanes): the measured HBM ceiling
  * the bench quotes next to the 8 TB/s datasheet peak. */
 int pebblegpu_probe_copy_gbps(int device, int lane_bytes, size_t bytes, int iters, float *gbps);
-/* normalizeIQ ingest helpers are a "next" row; not part of ABI v1. */
+/* Ingest on the device: DeviceInterfaceBase::normalizeIQ (pebblelib/deviceinterfacebase.cpp:648-838) and
+ * WavFile::ReadSamples' PCM16 scaling (wavfile.cpp:299-300).  d_src holds n_samples raw IQ pairs, d_dst receives float2.
+ * gain = m_userIQGain * m_normalizeIQGain; iq_order = DeviceInterface::IQOrder (device_interfaces.h:140-145). */
+typedef enum {
+    PEBBLEGPU_IQ_S8 = 0,    /* CPX8  (HackRF):  v / 128 */
+    PEBBLEGPU_IQ_U8 = 1,    /* CPXU8 (RTL2832): (v - 128) / 128 */
+    PEBBLEGPU_IQ_S16 = 2,   /* CPX16: v / 32768 */
+    PEBBLEGPU_IQ_F32 = 3,   /* CPXFLOAT */
+    PEBBLEGPU_IQ_WAV16 = 4  /* 16-bit PCM stereo WAV: v / 32767 */
+} pebblegpu_iq_format;
+typedef enum { PEBBLEGPU_IQO_IQ = 0, PEBBLEGPU_IQO_QI, PEBBLEGPU_IQO_IONLY, PEBBLEGPU_IQO_QONLY } pebblegpu_iq_order;
+int pebblegpu_normalize_iq(int device, int format, int iq_order, double gain, const void *d_src, uint64_t n_samples, void *d_dst);
 
 /* ------------------------------------------------------------------------------------------------
  * Receiver bank: C tuned channels over one shared wideband stream, or C independent streams.
@@ -145,6 +156,43 @@ int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);
  * spectrum_db (may be NULL) receives this frame's dB spectrum (bins doubles). */
 int pebblegpu_process_iq(pebblegpu_receiver *rx, const double *iq, uint16_t n, double *audio,
                          uint32_t *n_audio, double *spectrum_db);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stream bank: S independent full-rate IQ streams, each through the overlap-save band-pass
+ * (CFastFIR::ProcessData, pebblelib/fastfir.cpp:281-334, one filter per stream) and the display
+ * transform (FFT::fftSpectrum, pebblelib/fft.cpp:317-374) at the stream rate -- the two transforms of
+ * Receiver::processIQData with no tuner/decimator in front (BASELINE.json configs[4]: 64 streams,
+ * 65536-point spectrum, 2048/1025 band-pass).  Device buffers, one process per GPU, streams shard
+ * across ranks with no exchange.  frame/spectrum_bins: 2048-sample frames with 2048/4096/8192 bins
+ * (the reference's setup), or 65536/65536, which is past the reference's own m_maxFFTSize clamp
+ * (fft.h:21) and uses the same formulas with the clamp lifted.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pebblegpu_streambank pebblegpu_streambank;
+typedef struct pebblegpu_streambank_config {
+    uint32_t struct_size;
+    int32_t device;
+    double sample_rate;      /* stream rate, used by the band-pass design (fastfir.cpp:186-261) */
+    uint32_t n_streams;
+    uint32_t frame;          /* samples per spectrum frame */
+    uint32_t spectrum_bins;
+    uint32_t fastfir_fft;    /* 0 -> 2048 */
+    uint32_t fastfir_taps;   /* 0 -> 1025 */
+    uint32_t max_frames;     /* capacity per call, frames per stream */
+    uint32_t reserved[5];
+} pebblegpu_streambank_config;
+int pebblegpu_streambank_create(const pebblegpu_streambank_config *cfg, pebblegpu_streambank **out);
+int pebblegpu_streambank_destroy(pebblegpu_streambank *sb);
+/* CFastFIR::SetupParameters(lo, hi, 0, sample_rate) for one stream; E_FILTER_PARAM on the reference's
+ * "Filter Parameter error" (fastfir.cpp:201-208), the previous filter stays in place */
+int pebblegpu_streambank_set_bandpass(pebblegpu_streambank *sb, uint32_t stream, double lo, double hi);
+/* d_iq: [stream][n_samples] float2, n_samples a multiple of frame.  what: bit 0 band-pass, bit 1 spectrum */
+int pebblegpu_streambank_process(pebblegpu_streambank *sb, const void *d_iq, uint64_t n_samples, uint32_t what);
+/* filtered [stream][n_samples] float2 (row pitch returned); spectrum [stream][frames][bins] float dB */
+const void *pebblegpu_streambank_filtered(const pebblegpu_streambank *sb, uint64_t *samples_per_stream, uint64_t *pitch_samples);
+const void *pebblegpu_streambank_spectrum(const pebblegpu_streambank *sb, uint64_t *frames_per_stream, uint32_t *bins);
+/* which: 0 whole call, 1 band-pass kernel, 2 spectrum kernels */
+int pebblegpu_streambank_last_ms(const pebblegpu_streambank *sb, int which, float *ms);
+int pebblegpu_streambank_synchronize(pebblegpu_streambank *sb);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone process steps with the reference's per-class call shapes, host buffers in and out.

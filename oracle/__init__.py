@@ -84,6 +84,24 @@ def _ptr(a):
     return a.ctypes.data_as(_dp)
 
 
+def normalize_iq(raw, fmt, order=0, gain=1.0):
+    """DeviceInterfaceBase::normalizeIQ batch variants (pebblelib/deviceinterfacebase.cpp:648-838) and the WAV PCM16 scaling
+    (wavfile.cpp:299-300), restated in numpy (fp64).  fmt: 0 int8 /128, 1 uint8 (v-128)/128, 2 int16 /32768, 3 float32,
+    4 WAV int16 /32767.  order: 0 IQ, 1 QI, 2 I only, 3 Q only."""
+    v = np.asarray(raw).astype(np.float64).reshape(-1, 2)
+    if fmt == 1:
+        v = v - 128.0
+    scale = {0: 1 / 128.0, 1: 1 / 128.0, 2: 1 / 32768.0, 3: 1.0, 4: 1 / 32767.0}[fmt] * gain
+    i, q = v[:, 0] * scale, v[:, 1] * scale
+    if order == 0:
+        return i + 1j * q
+    if order == 1:
+        return q + 1j * i
+    if order == 2:
+        return i + 1j * i
+    return q + 1j * q
+
+
 class _MixerS(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fs", "freq", "inc", "osc_cos", "osc_sin", "last_re", "last_im")]
 

@@ -13,11 +13,14 @@ _LIBNAME = "libpebblegpu.so"
 SYMBOLS = [
     "pebblegpu_last_error", "pebblegpu_abi_version", "pebblegpu_device_count",
     "pebblegpu_malloc", "pebblegpu_free", "pebblegpu_memcpy_h2d", "pebblegpu_memcpy_d2h", "pebblegpu_memset",
-    "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps",
+    "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps", "pebblegpu_normalize_iq",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
     "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
+    "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
+    "pebblegpu_streambank_process", "pebblegpu_streambank_filtered", "pebblegpu_streambank_spectrum",
+    "pebblegpu_streambank_last_ms", "pebblegpu_streambank_synchronize",
     "pebblegpu_mixer_create", "pebblegpu_mixer_destroy", "pebblegpu_mixer_set_frequency", "pebblegpu_mixer_process",
     "pebblegpu_decimator_create", "pebblegpu_decimator_destroy", "pebblegpu_decimator_build_chain",
     "pebblegpu_decimator_dec_by2_stages", "pebblegpu_decimator_process",
@@ -40,6 +43,14 @@ class Config(C.Structure):
         ("frames_per_buffer", C.c_uint32), ("n_channels", C.c_uint32), ("shared_input", C.c_uint32),
         ("wfm", C.c_uint32), ("spectrum_bins", C.c_uint32), ("fastfir_fft", C.c_uint32),
         ("fastfir_taps", C.c_uint32), ("max_superframes", C.c_uint32), ("reserved", C.c_uint32 * 5),
+    ]
+
+
+class StreamBankConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("sample_rate", C.c_double), ("n_streams", C.c_uint32),
+        ("frame", C.c_uint32), ("spectrum_bins", C.c_uint32), ("fastfir_fft", C.c_uint32), ("fastfir_taps", C.c_uint32),
+        ("max_frames", C.c_uint32), ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -69,6 +80,7 @@ def _declare(L):
     L.pebblegpu_memcpy_d2h.argtypes = [i32, vp, vp, C.c_size_t]
     L.pebblegpu_memset.argtypes = [i32, vp, i32, C.c_size_t]
     L.pebblegpu_device_synchronize.argtypes = [i32]
+    L.pebblegpu_normalize_iq.argtypes = [i32, i32, i32, dbl, vp, u64, vp]
     L.pebblegpu_probe_copy_gbps.argtypes = [i32, i32, C.c_size_t, i32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.pebblegpu_receiver_destroy.argtypes = [vp]
@@ -85,6 +97,16 @@ def _declare(L):
     L.pebblegpu_receiver_mean_ms.argtypes = [vp, i32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_synchronize.argtypes = [vp]
     L.pebblegpu_process_iq.argtypes = [vp, dp, C.c_uint16, dp, C.POINTER(u32), dp]
+    L.pebblegpu_streambank_create.argtypes = [C.POINTER(StreamBankConfig), C.POINTER(vp)]
+    L.pebblegpu_streambank_destroy.argtypes = [vp]
+    L.pebblegpu_streambank_set_bandpass.argtypes = [vp, u32, dbl, dbl]
+    L.pebblegpu_streambank_process.argtypes = [vp, vp, u64, u32]
+    L.pebblegpu_streambank_filtered.restype = vp
+    L.pebblegpu_streambank_filtered.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.pebblegpu_streambank_spectrum.restype = vp
+    L.pebblegpu_streambank_spectrum.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+    L.pebblegpu_streambank_last_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    L.pebblegpu_streambank_synchronize.argtypes = [vp]
     # stand-alone steps
     L.pebblegpu_mixer_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
     L.pebblegpu_mixer_destroy.argtypes = [vp]
@@ -136,6 +158,25 @@ def probe_copy_gbps(lane_bytes=16, nbytes=1 << 30, iters=10, device=0, lib=None)
     g = C.c_float()
     check(L, L.pebblegpu_probe_copy_gbps(device, lane_bytes, nbytes, iters, C.byref(g)))
     return g.value
+
+
+IQ_S8, IQ_U8, IQ_S16, IQ_F32, IQ_WAV16 = range(5)
+IQO_IQ, IQO_QI, IQO_IONLY, IQO_QONLY = range(4)
+
+
+def normalize_iq(raw, fmt, order=IQO_IQ, gain=1.0, device=0, lib=None):
+    """raw: numpy array of interleaved I,Q in the device's native type -> complex64 array converted on the GPU"""
+    L = lib or load_library()
+    raw = np.ascontiguousarray(raw)
+    n = raw.size // 2
+    src = DeviceBuffer.from_array(raw, device, L)
+    dst = DeviceBuffer(8 * n, device, L)
+    try:
+        check(L, L.pebblegpu_normalize_iq(device, fmt, order, float(gain), C.c_void_p(src.ptr), n, C.c_void_p(dst.ptr)))
+        return dst.download(np.complex64, n)
+    finally:
+        src.free()
+        dst.free()
 
 
 class DeviceBuffer:
@@ -299,3 +340,82 @@ class ReceiverBank:
         check(self.L, self.L.pebblegpu_process_iq(self.h, x.ctypes.data_as(dp), len(x), audio.ctypes.data_as(dp), C.byref(n_audio),
                                                  spec.ctypes.data_as(dp) if spec is not None else None))
         return audio[: n_audio.value].copy(), spec
+
+
+class StreamBank:
+    """S full-rate streams through the overlap-save band-pass and the display transform (pebblegpu_streambank_*)."""
+
+    BANDPASS, SPECTRUM = 1, 2
+
+    def __init__(self, sample_rate, n_streams, frame=65536, spectrum_bins=65536, fastfir_fft=0, fastfir_taps=0,
+                 max_frames=1, device=0, lib=None):
+        self.L = lib or load_library()
+        cfg = StreamBankConfig()
+        cfg.struct_size = C.sizeof(StreamBankConfig)
+        cfg.device = device
+        cfg.sample_rate = float(sample_rate)
+        cfg.n_streams = n_streams
+        cfg.frame = frame
+        cfg.spectrum_bins = spectrum_bins
+        cfg.fastfir_fft = fastfir_fft
+        cfg.fastfir_taps = fastfir_taps
+        cfg.max_frames = max_frames
+        self.h = C.c_void_p()
+        check(self.L, self.L.pebblegpu_streambank_create(C.byref(cfg), C.byref(self.h)))
+        self.device, self.n_streams, self.frame = device, n_streams, frame
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.pebblegpu_streambank_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_bandpass(self, stream, lo, hi):
+        check(self.L, self.L.pebblegpu_streambank_set_bandpass(self.h, stream, float(lo), float(hi)))
+
+    def process_device(self, dptr, n_samples, what=3):
+        check(self.L, self.L.pebblegpu_streambank_process(self.h, C.c_void_p(dptr), int(n_samples), int(what)))
+
+    def synchronize(self):
+        check(self.L, self.L.pebblegpu_streambank_synchronize(self.h))
+
+    def last_ms(self, which=0):
+        ms = C.c_float()
+        check(self.L, self.L.pebblegpu_streambank_last_ms(self.h, which, C.byref(ms)))
+        return ms.value
+
+    def filtered(self):
+        n, pitch = C.c_uint64(), C.c_uint64()
+        p = self.L.pebblegpu_streambank_filtered(self.h, C.byref(n), C.byref(pitch))
+        self.synchronize()
+        out = np.empty((self.n_streams, int(n.value)), dtype=np.complex64)
+        if out.size:
+            check(self.L, self.L.pebblegpu_memcpy_d2h(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes))
+        return out
+
+    def spectrum(self):
+        f, b = C.c_uint64(), C.c_uint32()
+        p = self.L.pebblegpu_streambank_spectrum(self.h, C.byref(f), C.byref(b))
+        self.synchronize()
+        out = np.empty((self.n_streams, int(f.value), int(b.value)), dtype=np.float32)
+        if out.size:
+            check(self.L, self.L.pebblegpu_memcpy_d2h(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes))
+        return out
+
+    def process(self, iq, what=3):
+        """iq: complex [streams, n] -> (filtered [S, n] or None, spectrum [S, frames, bins] or None)"""
+        iq = np.atleast_2d(np.asarray(iq))
+        assert iq.shape[0] == self.n_streams
+        buf = DeviceBuffer.from_array(to_f32_iq(iq), self.device, self.L)
+        try:
+            self.process_device(buf.ptr, iq.shape[1], what)
+            y = self.filtered() if what & 1 else None
+            s = self.spectrum() if what & 2 else None
+        finally:
+            buf.free()
+        return y, s

@@ -180,6 +180,20 @@ void OscBank::advance(uint64_t n)
     }
 }
 
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst)
+{
+    double scale = gain;
+    if (fmt == 0 || fmt == 1) scale *= 1 / 128.0;        // deviceinterfacebase.cpp:651,689
+    else if (fmt == 2) scale *= 1 / 32768.0;             // :729
+    else if (fmt == 4) scale *= 1 / 32767.0;             // wavfile.cpp:299-300
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    launch(k_normalize_iq, dim3((unsigned)blocks), dim3(256), (hipStream_t) nullptr, d_src, d_dst, n, fmt, order, (float)scale);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
 // streaming-copy probe: the chip's practical HBM ceiling next to which the kernels are priced
 int probe_copy(int lane_bytes, size_t bytes, int iters, float *gbps)
 {
@@ -377,10 +391,29 @@ int FastFirCore::run(hipStream_t s, const HistBuf &in, long long n, float2 *out,
     const long long L = block_len();
     if (n % L != 0) return fail(PEBBLEGPU_E_SIZE, "FastFIR input %lld is not a multiple of its block %lld", n, L);
     const dim3 grid((unsigned)(n / L), C), block(256);
-    if (fft_n == 2048) launch(k_fastfir<2048>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap);
-    else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap);
-    else launch(k_fastfir<8192>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap);
+    const float2 *no_tail = nullptr;
+    if (fft_n == 2048) launch(k_fastfir<2048>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
+    else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
+    else launch(k_fastfir<8192>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     PG_HIP(hipGetLastError());
+    return 0;
+}
+int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, float2 *d_tail, long long n, float2 *out, long long out_pitch)
+{
+    const int overlap = (int)taps - 1;
+    const long long L = block_len();
+    if (n % L != 0) return fail(PEBBLEGPU_E_SIZE, "FastFIR input %lld is not a multiple of its block %lld", n, L);
+    if (n < overlap) return fail(PEBBLEGPU_E_SIZE, "FastFIR input %lld is shorter than its overlap %d", n, overlap);
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)(n / L), C), block(256);
+    const float2 *tail = d_tail;
+    if (fft_n == 2048) launch(k_fastfir<2048>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
+    else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
+    else launch(k_fastfir<8192>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
+    PG_HIP(hipGetLastError());
+    // m_pFFTOverlapBuf <- last taps-1 input samples of every row (fastfir.cpp:312-316); ordered after the kernel on s
+    PG_HIP(hipMemcpy2DAsync(d_tail, sizeof(float2) * (size_t)overlap, in + (n - overlap), sizeof(float2) * (size_t)in_pitch,
+                            sizeof(float2) * (size_t)overlap, C, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -642,7 +675,9 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     bins = fft_size;
     if (bins < 2048) bins = 2048;    // fft.cpp:74-75
     if (bins > 65535) bins = 65535;  // fft.cpp:76-77 (and then not a power of two)
-    if (nf != 2048 || !(bins == 2048 || bins == 4096 || bins == 8192))
+    big = frame == (uint32_t)kBigN && fft_size == (uint32_t)kBigN;  // BASELINE config 5: past the fft.h:21 clamp on purpose
+    if (big) bins = kBigN;
+    if (!big && (nf != 2048 || !(bins == 2048 || bins == 4096 || bins == 8192)))
         return fail(PEBBLEGPU_E_UNSUPPORTED, "spectrum needs 2048-sample frames and 2048/4096/8192 bins in this build (asked %u/%u)", nf, bins);
     std::vector<double> w;
     const double cg = design::blackman_harris(nf, w);
@@ -652,6 +687,15 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     PG_HIP(hipMemcpy(d_window, wf.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
     // btab[q][m] = exp(-2*pi*i*(64*m*q)/bins): the wave-uniform factor of the pruned-FFT pre-twiddle W_bins^{n q},
     // n = lane + 64 m (the per-lane factor W_bins^{lane q} is computed in the kernel)
+    if (big) {
+        std::vector<float2> w32(32);
+        for (int m = 0; m < 32; m++) {
+            const double a = -design::kTwoPi * (double)m / 32.0;
+            w32[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        PG_HIP(hipMalloc((void **)&d_w32, sizeof(float2) * 32));
+        PG_HIP(hipMemcpy(d_w32, w32.data(), sizeof(float2) * 32, hipMemcpyHostToDevice));
+    }
     const uint32_t zp = bins / nf;
     std::vector<float2> bt((size_t)zp * 32);
     for (uint32_t q = 0; q < zp; q++)
@@ -672,15 +716,39 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf};
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_w32, d_Y};
     for (void *q : p) if (q) (void)hipFree(q);
-    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr;
+    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_w32 = d_Y = nullptr;
+    y_cap = 0;
 }
 int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out)
 {
     SpectrumParams sp;
     sp.in_pitch = in_pitch;
     sp.n_frames = F;
+    if (big) {
+        if (F == 0) return 0;
+        const size_t need = (size_t)S * (size_t)F * kBigN;
+        if (need > y_cap) {
+            PG_HIP(hipStreamSynchronize(s));
+            if (d_Y) (void)hipFree(d_Y);
+            d_Y = nullptr;
+            y_cap = 0;
+            PG_HIP(hipMalloc((void **)&d_Y, sizeof(float2) * need));
+            y_cap = need;
+        }
+        long long G = (F * (long long)S * 8) / 2048;  // ~2048 workgroups before frames are chained in one group
+        G = G < 1 ? 1 : (G > 16 ? 16 : G);
+        sp.frames_per_group = (int)G;
+        sp.scale = scale;
+        sp.out_pitch = F * (long long)bins;
+        launch(k_big_cols, dim3((unsigned)(F * 8), S), dim3(256), s, d_in, (long long)in_pitch, d_Y, (const float *)d_window, (const float2 *)d_w32, (long long)F);
+        launch(k_big_rows, dim3((unsigned)(cdiv(F, G) * 8), S), dim3(256), s, (const float2 *)d_Y, d_out, (const float2 *)d_tw_nf,
+               (const float *)d_prev[parity], d_prev[parity ^ 1], sp);
+        parity ^= 1;
+        PG_HIP(hipGetLastError());
+        return 0;
+    }
     const int groups = 4 / (int)(bins / nf);  // wave groups (frames in flight) per workgroup
     long long G = (F * (long long)S) / (1024 * groups);  // aim for ~1024 workgroups; each group recomputes one extra frame
     G = G < 1 ? 1 : (G > 16 ? 16 : G);

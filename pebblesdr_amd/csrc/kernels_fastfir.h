@@ -6,7 +6,8 @@
 // passes share the register layout (fft_lds.h), so the product needs no exchange.
 //
 // The input buffer carries taps-1 samples of head-room holding the previous call's tail, which is
-// exactly m_pFFTOverlapBuf (zero before the first call, fastfir.cpp:104-105).
+// exactly m_pFFTOverlapBuf (zero before the first call, fastfir.cpp:104-105).  A caller-owned buffer
+// without head-room passes `tail` instead ([channel][taps-1], refreshed by the host side after the call).
 //
 // Bound: HBM.  Algorithmic bytes per demod-rate sample: 8 read + 8 written (+ H once per block: with
 // taps-1 = N/2 the overlap doubles the read to 16 B unless L2 serves the second touch).
@@ -19,7 +20,7 @@ template <int N>
 __global__ __launch_bounds__(256) void k_fastfir(const float2 *__restrict__ in, long long in_pitch,
                                                   float2 *__restrict__ out, long long out_pitch,
                                                   const float2 *__restrict__ H, const float2 *__restrict__ tw,
-                                                  int overlap /* taps-1 */)
+                                                  int overlap /* taps-1 */, const float2 *__restrict__ tail)
 {
     constexpr int E = N / 256;
     __shared__ float2 lds[FftLds<N>::kSlots];
@@ -29,8 +30,17 @@ __global__ __launch_bounds__(256) void k_fastfir(const float2 *__restrict__ in, 
     const float2 *x = in + (long long)c * in_pitch + b * L - overlap;  // first sample of [overlap | new]
     const float2 *h = H + (long long)c * N;
     float2 v[E];
+    if (tail != nullptr && b == 0) {  // caller's buffer has no head-room: the overlap of block 0 lives in `tail` [c][overlap]
+        const float2 *t = tail + (long long)c * overlap;
 #pragma unroll
-    for (int m = 0; m < E; m++) v[m] = x[tid + 256 * m];
+        for (int m = 0; m < E; m++) {
+            const int i = tid + 256 * m;
+            v[m] = i < overlap ? t[i] : x[i];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; m++) v[m] = x[tid + 256 * m];
+    }
     fft_regs<N, +1>(v, lds, tw, tid);
 #pragma unroll
     for (int m = 0; m < E; m++) v[m] = cmul(h[tid + 256 * m], v[m]);  // CpxMpy, fastfir.cpp:325-334

@@ -267,6 +267,41 @@ static __global__ __launch_bounds__(256) void k_save_tail(float2 *__restrict__ d
     b[-hist + j] = b[n - hist + j];
 }
 
+// DeviceInterfaceBase::normalizeIQ on the device (pebblelib/deviceinterfacebase.cpp:648-838) and WavFile::ReadSamples'
+// PCM16 scaling (wavfile.cpp:299-300): raw device samples -> float2, gain and IQ order applied.  Uploading the raw
+// 2 or 4 bytes per sample instead of converted doubles cuts the host->device traffic 4-8x.
+//   fmt 0: CPX8  int8 pairs,  v * (1/128) * gain          fmt 1: CPXU8 uint8 pairs, (v - 128) * (1/128) * gain
+//   fmt 2: CPX16 int16 pairs, v * (1/32768) * gain        fmt 3: CPXFLOAT, v * gain       fmt 4: WAV PCM16, v / 32767 * gain
+//   order 0 IQ, 1 QI, 2 I only, 3 Q only  (DeviceInterface::IQOrder, device_interfaces.h:140-145)
+static __global__ __launch_bounds__(256) void k_normalize_iq(const void *__restrict__ src, float2 *__restrict__ dst, long long n, int fmt,
+                                                              int order, float scale)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float a, b;
+        if (fmt == 0) {
+            const char2 v = reinterpret_cast<const char2 *>(src)[i];
+            a = (float)v.x; b = (float)v.y;
+        } else if (fmt == 1) {
+            const uchar2 v = reinterpret_cast<const uchar2 *>(src)[i];
+            a = (float)v.x - 128.0f; b = (float)v.y - 128.0f;
+        } else if (fmt == 2 || fmt == 4) {
+            const short2 v = reinterpret_cast<const short2 *>(src)[i];
+            a = (float)v.x; b = (float)v.y;
+        } else {
+            const float2 v = reinterpret_cast<const float2 *>(src)[i];
+            a = v.x; b = v.y;
+        }
+        a *= scale;
+        b *= scale;
+        float2 o;
+        if (order == 0) o = make_float2(a, b);
+        else if (order == 1) o = make_float2(b, a);
+        else if (order == 2) o = make_float2(a, a);
+        else o = make_float2(b, b);
+        dst[i] = o;
+    }
+}
+
 // Bandwidth probes for the roofline (bench.py): plain streaming copies with 16-byte and 8-byte lanes.
 static __global__ __launch_bounds__(256) void k_probe_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n)
 {

@@ -156,4 +156,121 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 65536-point spectrum (BASELINE config 5; beyond the reference's own m_maxFFTSize = 65535 clamp, fft.h:21 -- the
+// oracle lifts the clamp, everything else is FFT::fftSpectrum unchanged).  Frame = 65536 samples, window 65536, no
+// zero padding.  Four-step split N = 32 x 2048 with n = 2048*n1 + n2, k = k1 + 32*k2:
+//   X[k1 + 32 k2] = sum_{n2} W_2048^{n2 k2} * [ W_N^{n2 k1} * sum_{n1} w[n] x[n] W_32^{n1 k1} ]
+//   pass A (k_big_cols): one work-item per n2 does the 32-point DFT over n1 in registers (every load and store is
+//           lane-contiguous, no LDS), applies window and the W_N^{n2 k1} twiddle, writes Y[k1][n2];
+//   pass B (k_big_rows): one wave per row k1 runs the 2048-point wave transform (fft_lds.h), amplitude, previous-frame
+//           average (kept in registers over the frame loop), dB; four waves (k1 = 4a..4a+3) interleave their bins.
+// Bound: HBM; algorithmic bytes per frame 8*N + 4*N, plus the 2 x 8*N intermediate (written once, read once).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBigN = 65536, kBigR = 32, kBigM = 2048;
+
+// 32-point DFT in registers as 8 x 4 (n1 = 4*na + nb): DFT8 over na, twiddle W32^{nb*ka}, DFT4 over nb.
+// in: u[n1]; out: X[ka + 8*kb] left in u[4*ka + kb]  (read through perm32)
+__device__ __forceinline__ constexpr int perm32(int k) { return 4 * (k & 7) + (k >> 3); }
+__device__ __forceinline__ void dft32(float2 *u, const float2 *__restrict__ w32)
+{
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) {
+        float2 t[8];
+#pragma unroll
+        for (int na = 0; na < 8; na++) t[na] = u[nb + 4 * na];
+        bfly8<+1>(t);
+#pragma unroll
+        for (int ka = 0; ka < 8; ka++) u[4 * ka + nb] = nb == 0 ? t[ka] : cmul(t[ka], w32[(nb * ka) & 31]);
+    }
+#pragma unroll
+    for (int ka = 0; ka < 8; ka++) bfly4<+1>(u + 4 * ka);  // over nb: u[4*ka + kb] = X[ka + 8*kb]
+}
+
+// grid (frames * 8, S), block 256.  Y layout: [stream][frame][k1][n2]
+static __global__ __launch_bounds__(256) void k_big_cols(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ Y,
+                                                         const float *__restrict__ window, const float2 *__restrict__ w32,
+                                                         long long n_frames)
+{
+    const int s = blockIdx.y;
+    const long long f = blockIdx.x >> 3;
+    const int n2 = ((blockIdx.x & 7) << 8) + threadIdx.x;
+    const float2 *x = in + (long long)s * in_pitch + f * kBigN + n2;
+    float2 u[kBigR];
+#pragma unroll
+    for (int n1 = 0; n1 < kBigR; n1++) u[n1] = cscale(x[(long long)kBigM * n1], window[kBigM * n1 + n2]);
+    dft32(u, w32);
+    float2 *y = Y + ((long long)s * n_frames + f) * kBigN + n2;
+#pragma unroll
+    for (int k1 = 0; k1 < kBigR; k1++) {
+        const float2 tw = cis_cycles(-(double)(n2 * k1) / (double)kBigN);  // W_N^{n2 k1}
+        y[(long long)kBigM * k1] = cmul(u[perm32(k1)], tw);
+    }
+}
+
+// grid (ceil(n_frames / G) * 8, S), block 256 = 4 waves = rows k1 = 4a .. 4a+3 of one frame at a time
+static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__restrict__ Y, float *__restrict__ out,
+                                                             const float2 *__restrict__ tw_nf, const float *__restrict__ prev_in,
+                                                             float *__restrict__ prev_out, SpectrumParams sp)
+{
+    constexpr int E = 32;
+    __shared__ float2 lds[4][FftLds<kBigM>::kSlots];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.y, a = blockIdx.x & 7;
+    const int k1 = 4 * a + wave;
+    const int G = sp.frames_per_group;
+    const long long f0 = (long long)(blockIdx.x >> 3) * G;
+    float2 *my = lds[wave];
+    float *stage = reinterpret_cast<float *>(my);
+    float pa[E];
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        const bool live = f < sp.n_frames;
+        int ln = lane;
+        opaque(ln);
+        if (live && f < 0) {
+            const float *pp = prev_in + (long long)s * kBigN + k1 + 32 * ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) pa[m] = pp[32 * 64 * m];
+        } else if (live) {
+            const float2 *row = Y + (((long long)s * sp.n_frames + f) * kBigR + k1) * kBigM + ln;
+            float2 v[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) v[m] = row[64 * m];
+            fft_regs<kBigM, +1, 64>(v, my, tw_nf, ln);
+            float *st = stage + ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const float amp = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y) * sp.scale;
+                const float av = 0.5f * (amp + pa[m]);
+                st[64 * m] = fminf(fmaxf(6.02059991327962f * __builtin_amdgcn_logf(av), -120.f), 0.f);
+                pa[m] = amp;
+            }
+            if (f == sp.n_frames - 1) {
+                float *pp = prev_out + (long long)s * kBigN + k1 + 32 * ln;
+#pragma unroll
+                for (int m = 0; m < E; m++) pp[32 * 64 * m] = pa[m];
+            }
+        }
+        __syncthreads();
+        if (it >= 0 && live) {
+            // bins k = 4a + w + 32*j, w = 0..3: each lane stores 4 adjacent bins of one j
+            float *yf = out + (long long)s * sp.out_pitch + f * (long long)kBigN;
+#pragma unroll
+            for (int i = 0; i < kBigM / 256; i++) {
+                const int j = tid + 256 * i;
+                float4 d;
+                d.x = reinterpret_cast<const float *>(lds[0])[j];
+                d.y = reinterpret_cast<const float *>(lds[1])[j];
+                d.z = reinterpret_cast<const float *>(lds[2])[j];
+                d.w = reinterpret_cast<const float *>(lds[3])[j];
+                const int u = (4 * a + 32 * j + kBigN / 2) & (kBigN - 1);  // unfold, fft.cpp:207-213
+                *reinterpret_cast<float4 *>(yf + u) = d;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace pg

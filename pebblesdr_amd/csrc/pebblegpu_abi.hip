@@ -8,7 +8,10 @@ struct pebblegpu_receiver {
 };
 
 using pg::fail;
-namespace pg { int probe_copy(int lane_bytes, size_t bytes, int iters, float *gbps); }
+namespace pg {
+int probe_copy(int lane_bytes, size_t bytes, int iters, float *gbps);
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst);
+}
 
 extern "C" {
 
@@ -74,6 +77,14 @@ int pebblegpu_probe_copy_gbps(int device, int lane_bytes, size_t bytes, int iter
     if (!gbps || iters <= 0 || bytes < 4096 || (lane_bytes != 8 && lane_bytes != 16)) return fail(PEBBLEGPU_E_INVALID, "bad argument");
     if (int rc = need_device(device)) return rc;
     return pg::probe_copy(lane_bytes, bytes & ~(size_t)4095, iters, gbps);
+}
+
+int pebblegpu_normalize_iq(int device, int format, int iq_order, double gain, const void *d_src, uint64_t n_samples, void *d_dst)
+{
+    if (!d_src || !d_dst || format < 0 || format > PEBBLEGPU_IQ_WAV16 || iq_order < 0 || iq_order > 3 || n_samples == 0)
+        return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = need_device(device)) return rc;
+    return pg::run_normalize_iq(format, iq_order, gain, d_src, (long long)n_samples, (float2 *)d_dst);
 }
 
 int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out)

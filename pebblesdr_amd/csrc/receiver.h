@@ -90,6 +90,8 @@ struct FastFirCore {
     int design(hipStream_t s, uint32_t ch, double lo, double hi, double offset, double rate, bool *ok);
     // in: buffer with taps-1 head-room; n multiple of block_len()
     int run(hipStream_t s, const HistBuf &in, long long n, float2 *out, long long out_pitch);
+    // caller-owned rows without head-room; d_tail [C][taps-1] carries the overlap between calls and is refreshed here
+    int run_ext(hipStream_t s, const float2 *in, long long in_pitch, float2 *d_tail, long long n, float2 *out, long long out_pitch);
 };
 
 // ---- Demod_AM ----
@@ -154,6 +156,10 @@ struct SpectrumCore {
     float *d_prev[2] = {nullptr, nullptr};
     float *d_window = nullptr;
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
+    // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): W32 table and the [S][F][32][2048] intermediate
+    bool big = false;
+    float2 *d_w32 = nullptr, *d_Y = nullptr;
+    size_t y_cap = 0;
     float scale = 0;
     int parity = 0;
     int init(uint32_t streams, uint32_t frame, uint32_t fft_size);

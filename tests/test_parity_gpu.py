@@ -478,6 +478,118 @@ def test_bank_with_every_narrow_demod_mode(gpu_lib, oracle_mod):
                 assert rel_rms(g[c][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL
 
 
+@pytest.mark.parametrize("fmt,dtype,lo,hi", [(0, np.int8, -128, 127), (1, np.uint8, 0, 255), (2, np.int16, -32768, 32767), (4, np.int16, -32768, 32767)])
+def test_ingest_normalize_iq_integer_formats(gpu_lib, oracle_mod, fmt, dtype, lo, hi):
+    """normalizeIQ for every integer device format, all four IQ orders, with a gain.  fp32 results of
+    small-integer arithmetic: exact to the last bit of the float product, so the bar is 1e-7 relative."""
+    from pebblesdr_amd import binding as B
+    rng = np.random.RandomState(fmt)
+    raw = rng.randint(lo, hi + 1, size=2 * 10007).astype(dtype)
+    raw[:4] = [lo, hi, hi, lo]
+    for order in range(4):
+        g = B.normalize_iq(raw, fmt, order, gain=0.5)
+        r = oracle_mod.normalize_iq(raw, fmt, order, gain=0.5)
+        assert np.abs(g - r).max() <= 1e-7 * max(1.0, np.abs(r).max())
+
+
+def test_ingest_normalize_iq_float(gpu_lib, oracle_mod):
+    from pebblesdr_amd import binding as B
+    raw = lcg_noise(5000, 3, 2.0).astype(np.complex64).view(np.float32)
+    g = B.normalize_iq(raw, B.IQ_F32, B.IQO_QI, gain=1.5)
+    r = oracle_mod.normalize_iq(raw, 3, 1, gain=1.5)
+    assert np.abs(g - r).max() <= 2e-7 * np.abs(r).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 5: bank of full-rate streams, overlap-save band-pass + 65536-point display transform
+# ------------------------------------------------------------------------------------------------
+def _streambank_refs(oracle_mod, fs, bands, N):
+    refs = []
+    for lo, hi in bands:
+        f = oracle_mod.FastFIR(2048, 1025)
+        f.setup(lo, hi, 0.0, fs)
+        refs.append((f, oracle_mod.Spectrum(N, N, lift_clamp=True)))
+    return refs
+
+
+def test_config5_streambank_small(gpu_lib, oracle_mod):
+    """3 streams x 3 calls x 2 frames of 65536: every stream has its own filter; the band-pass overlap and the
+    spectrum's previous-frame average carry across calls (fastfir.cpp:312-316, fft.cpp:349-353)."""
+    import pebblesdr_amd as P
+    fs, S, N, F = 2.0e6, 3, 65536, 2
+    bands = [(-50e3, 50e3), (-100e3, -10e3), (300.0, 3000.0)]
+    x = np.stack([tones(fs, 3 * F * N, [(0.4, 123456.7 * (c + 1)), (0.01, -700001.3), (0.2, 20000.0 - 30000.0 * c), (0.1, 1700.0)])
+                  + lcg_noise(3 * F * N, 70 + c, 1e-4) for c in range(S)])
+    sb = P.StreamBank(fs, S, frame=N, spectrum_bins=N, max_frames=F)
+    for c in range(S):
+        sb.set_bandpass(c, *bands[c])
+    refs = _streambank_refs(oracle_mod, fs, bands, N)
+    for call in range(3):
+        blk = x[:, call * F * N:(call + 1) * F * N]
+        y, sp = sb.process(blk)
+        assert y.shape == (S, F * N) and sp.shape == (S, F, N)
+        for c in range(S):
+            assert rel_rms(y[c], refs[c][0].process(blk[c])) <= TOL
+            for f in range(F):
+                r = refs[c][1].process(blk[c, f * N:(f + 1) * N])
+                if call or f:
+                    assert db_err(sp[c, f], r) <= TOL_DB
+
+
+def test_config5_streambank_full_size(gpu_lib, oracle_mod):
+    """BASELINE configs[4] at size: 64 streams x 8 frames (33.5 M samples per call, frames chained two per wave group).
+    Oracle on three whole streams; for all 64, call-splitting invariance (one 8-frame call == eight 1-frame calls:
+    bit-exact, both carry states are exact) and a bin-centred tone reading its level at its bin in every frame."""
+    import pebblesdr_amd as P
+    fs, S, N, F = 2.0e6, 64, 65536, 8
+    t = np.arange(F * N) / fs
+    x = np.empty((S, F * N), dtype=np.complex64)
+    kbin = [1000 + 37 * c for c in range(S)]
+    for c in range(S):
+        x[c] = (10 ** (-10 / 20) * np.exp(2j * np.pi * (fs * kbin[c] / N) * t) + lcg_noise(F * N, 500 + c, 1e-4)).astype(np.complex64)
+    bands = [(-50e3 - 1e3 * c, 120e3 + 500.0 * c) for c in range(S)]  # every stream's tone is in band (fp32 floor otherwise)
+    a = P.StreamBank(fs, S, frame=N, spectrum_bins=N, max_frames=F)
+    b = P.StreamBank(fs, S, frame=N, spectrum_bins=N, max_frames=1)
+    for c in range(S):
+        a.set_bandpass(c, *bands[c])
+        b.set_bandpass(c, *bands[c])
+    YA, SA = a.process(x)
+    parts = [b.process(x[:, f * N:(f + 1) * N]) for f in range(F)]
+    assert np.array_equal(YA, np.concatenate([p[0] for p in parts], axis=1))
+    assert np.array_equal(SA, np.concatenate([p[1] for p in parts], axis=1))
+    for c in range(S):
+        assert np.all(np.argmax(SA[c, 1:], axis=1) == N // 2 + kbin[c])
+        assert np.abs(SA[c, 1:].max(axis=1) + 10.0).max() < 2e-3
+    for c in (0, 17, 63):
+        f_ref, s_ref = _streambank_refs(oracle_mod, fs, [bands[c]], N)[0]
+        assert rel_rms(YA[c], f_ref.process(x[c])) <= TOL
+        for f in range(F):
+            r = s_ref.process(x[c, f * N:(f + 1) * N])
+            if f:
+                assert db_err(SA[c, f], r) <= TOL_DB
+
+
+def test_config5_error_paths(gpu_lib):
+    import pebblesdr_amd as P
+    sb = P.StreamBank(2.0e6, 2, frame=65536, spectrum_bins=65536, max_frames=1)
+    with pytest.raises(P.PebbleGpuError) as e:
+        sb.set_bandpass(0, 3000, 300)
+    assert e.value.code == -4
+    with pytest.raises(P.PebbleGpuError) as e:
+        sb.set_bandpass(2, -1000, 1000)
+    assert e.value.code == -1
+    buf = P.DeviceBuffer(8 * 2 * 65536)
+    with pytest.raises(P.PebbleGpuError) as e:
+        sb.process_device(buf.ptr, 1000)
+    assert e.value.code == -5
+    with pytest.raises(P.PebbleGpuError) as e:
+        sb.process_device(buf.ptr, 2 * 65536)  # above max_frames
+    assert e.value.code == -5
+    with pytest.raises(P.PebbleGpuError) as e:
+        P.StreamBank(2.0e6, 2, frame=65536, spectrum_bins=32768)
+    assert e.value.code == -6
+
+
 def test_error_paths(gpu_lib):
     import pebblesdr_amd as P
     rx = P.ReceiverBank(2048000, 2, True, False, 0)

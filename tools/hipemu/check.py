@@ -175,7 +175,30 @@ def case_receiver():
     return ok
 
 
-CASES = {"spectrum": case_spectrum, "mixer": case_mixer, "decimator": case_decimator, "fastfir": case_fastfir,
+def case_streambank():
+    ok = True
+    fs, S, N = 2.0e6, 2, 65536
+    x = np.stack([tones(fs, 2 * N, [(0.4, 123456.7), (0.01, -700001.3), (0.2, 20000.0)]) + lcg_noise(2 * N, 7, 1e-4),
+                  tones(fs, 2 * N, [(0.3, -40000.0), (0.05, 500000.0)]) + lcg_noise(2 * N, 8, 1e-3)])
+    bands = [(-50e3, 50e3), (-100e3, -10e3)]
+    sb = B.StreamBank(fs, S, frame=N, spectrum_bins=N, max_frames=1, lib=L)
+    refs = []
+    for c in range(S):
+        sb.set_bandpass(c, *bands[c])
+        f = O.FastFIR(2048, 1025); f.setup(bands[c][0], bands[c][1], 0.0, fs)
+        refs.append((f, O.Spectrum(N, N, lift_clamp=True)))
+    for call in range(2):
+        blk = x[:, call * N:(call + 1) * N]
+        y, sp = sb.process(blk)
+        for c in range(S):
+            ry = refs[c][0].process(blk[c]); rs = refs[c][1].process(blk[c])
+            ok &= report("streambank call %d stream %d band-pass" % (call, c), rel_rms(y[c], ry), 5e-6)
+            m = rs > -100
+            ok &= report("streambank call %d stream %d 65536 bins max|dB|" % (call, c), float(np.abs(sp[c, 0] - rs)[m].max()), 0.05)
+    return ok
+
+
+CASES = {"streambank": case_streambank, "spectrum": case_spectrum, "mixer": case_mixer, "decimator": case_decimator, "fastfir": case_fastfir,
          "demod": case_demod, "receiver": case_receiver}
 
 if __name__ == "__main__":

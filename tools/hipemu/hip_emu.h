@@ -32,6 +32,9 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
 struct uint2 { unsigned x, y; };
+struct char2 { signed char x, y; };
+struct uchar2 { unsigned char x, y; };
+struct short2 { short x, y; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
