@@ -39,17 +39,22 @@ inline void launch_lds(void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds_
 }
 
 // ---- small complex helpers on float2 ----
+// Written with float2's own vector operators (native <2 x float> underneath) so that a complex value stays one
+// aligned register pair and the arithmetic becomes v_pk_add/mul/fma_f32 with op_sel/neg modifiers.  Component-wise
+// scalar code makes the compiler scatter re/im over unrelated registers and gather them again with v_mov before
+// every packed instruction (a third of the VALU stream in the FFT kernels).
+__device__ __forceinline__ float2 cswap(float2 a) { return make_float2(a.y, a.x); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(a.x, a.x) * b + make_float2(-a.y, a.y) * cswap(b);
 }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b)  // a * conj(b)
 {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    return make_float2(b.x, b.x) * a + make_float2(b.y, -b.y) * cswap(a);
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return a * make_float2(s, s); }
 
 // Wave-private LDS hand-off: lanes of one wave run in lockstep and its LDS operations retire in order, so
 // this only has to stop the compiler from moving LDS accesses across the point (no s_barrier is emitted).

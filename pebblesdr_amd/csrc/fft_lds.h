@@ -55,11 +55,10 @@ template <int DIR> __device__ __forceinline__ void bfly8(float2 *u)
     bfly4<DIR>(o);
     const float c = 0.70710678118654752440f;
     // W8^1 = c(1 - j*DIR), W8^2 = -j*DIR, W8^3 = c(-1 - j*DIR)
-    float2 o1 = DIR > 0 ? make_float2(c * (o[1].x + o[1].y), c * (o[1].y - o[1].x))
-                         : make_float2(c * (o[1].x - o[1].y), c * (o[1].y + o[1].x));
+    // W8^1 * o = c (o + mul_mj(o)),  W8^3 * o = c (mul_mj(o) - o)
+    float2 o1 = cscale(cadd(o[1], mul_mj<DIR>(o[1])), c);
     float2 o2 = mul_mj<DIR>(o[2]);
-    float2 o3 = DIR > 0 ? make_float2(c * (o[3].y - o[3].x), -c * (o[3].x + o[3].y))
-                         : make_float2(-c * (o[3].x + o[3].y), c * (o[3].x - o[3].y));
+    float2 o3 = cscale(csub(mul_mj<DIR>(o[3]), o[3]), c);
     u[0] = cadd(e[0], o[0]); u[4] = csub(e[0], o[0]);
     u[1] = cadd(e[1], o1);   u[5] = csub(e[1], o1);
     u[2] = cadd(e[2], o2);   u[6] = csub(e[2], o2);

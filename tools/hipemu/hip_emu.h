@@ -29,6 +29,9 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float2 { float x, y; };
+static inline float2 operator+(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }
+static inline float2 operator-(float2 a, float2 b) { return float2{a.x - b.x, a.y - b.y}; }
+static inline float2 operator*(float2 a, float2 b) { return float2{a.x * b.x, a.y * b.y}; }
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
 struct uint2 { unsigned x, y; };
