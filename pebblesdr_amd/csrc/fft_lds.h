@@ -38,14 +38,24 @@ template <int DIR> __device__ __forceinline__ void bfly2(float2 *u)
     u[0] = cadd(a, b);
     u[1] = csub(a, b);
 }
+// a + (-j*DIR) b and a - (-j*DIR) b as one packed FMA each: (-j*DIR) b = swap(b) * (DIR, -DIR).  (A swap folds into
+// the instruction's op_sel; a half negation does not and would cost two extra moves per use.)
+template <int DIR> __device__ __forceinline__ float2 add_mj(float2 a, float2 b)
+{
+    return cswap(b) * make_float2((float)DIR, (float)-DIR) + a;
+}
+template <int DIR> __device__ __forceinline__ float2 sub_mj(float2 a, float2 b)
+{
+    return cswap(b) * make_float2((float)-DIR, (float)DIR) + a;
+}
 template <int DIR> __device__ __forceinline__ void bfly4(float2 *u)
 {
     float2 t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]);
-    float2 t2 = cadd(u[1], u[3]), t3 = mul_mj<DIR>(csub(u[1], u[3]));
+    float2 t2 = cadd(u[1], u[3]), d = csub(u[1], u[3]);
     u[0] = cadd(t0, t2);
     u[2] = csub(t0, t2);
-    u[1] = cadd(t1, t3);
-    u[3] = csub(t1, t3);
+    u[1] = add_mj<DIR>(t1, d);
+    u[3] = sub_mj<DIR>(t1, d);
 }
 template <int DIR> __device__ __forceinline__ void bfly8(float2 *u)
 {
@@ -54,15 +64,13 @@ template <int DIR> __device__ __forceinline__ void bfly8(float2 *u)
     bfly4<DIR>(e);
     bfly4<DIR>(o);
     const float c = 0.70710678118654752440f;
-    // W8^1 = c(1 - j*DIR), W8^2 = -j*DIR, W8^3 = c(-1 - j*DIR)
-    // W8^1 * o = c (o + mul_mj(o)),  W8^3 * o = c (mul_mj(o) - o)
-    float2 o1 = cscale(cadd(o[1], mul_mj<DIR>(o[1])), c);
-    float2 o2 = mul_mj<DIR>(o[2]);
-    float2 o3 = cscale(csub(mul_mj<DIR>(o[3]), o[3]), c);
+    // W8^1 = c(1 - j*DIR), W8^2 = -j*DIR, W8^3 = c(-1 - j*DIR):  W8^1 o = c (o + mj o),  W8^3 o = -c (o - mj o)
+    const float2 o1 = cscale(add_mj<DIR>(o[1], o[1]), c);
+    const float2 o3 = cscale(sub_mj<DIR>(o[3], o[3]), c);
     u[0] = cadd(e[0], o[0]); u[4] = csub(e[0], o[0]);
     u[1] = cadd(e[1], o1);   u[5] = csub(e[1], o1);
-    u[2] = cadd(e[2], o2);   u[6] = csub(e[2], o2);
-    u[3] = cadd(e[3], o3);   u[7] = csub(e[3], o3);
+    u[2] = add_mj<DIR>(e[2], o[2]); u[6] = sub_mj<DIR>(e[2], o[2]);
+    u[3] = csub(e[3], o3);   u[7] = cadd(e[3], o3);
 }
 template <int R, int DIR> __device__ __forceinline__ void bfly(float2 *u)
 {
@@ -105,6 +113,8 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[N / T], float2 *lds, const 
         if (R == 8) w4 = twid<DIR>(tw[4 * i1]);
     };
     if (P > 1 && P <= T) fetch_tw(tid & (P - 1));
+    const int jbase = (P <= T) ? (tid - (tid & (P - 1))) * R + (tid & (P - 1)) : tid;
+    float2 *wbase = lds + lpad(jbase);
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int b = tid + T * q;
@@ -114,16 +124,17 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[N / T], float2 *lds, const 
         const int k = b & (P - 1);
         if (P > 1) {
             if (P > T) fetch_tw(k);
-            u[1] = cmul(u[1], w1);
+            // twiddle first: cmul builds (-a.y, a.y) from its first argument, which is per-pass constant when P <= T
+            u[1] = cmul(w1, u[1]);
             if (R >= 4) {
                 const float2 w3 = cmul(w1, w2);
-                u[2] = cmul(u[2], w2);
-                u[3] = cmul(u[3], w3);
+                u[2] = cmul(w2, u[2]);
+                u[3] = cmul(w3, u[3]);
                 if (R == 8) {
-                    u[4] = cmul(u[4], w4);
-                    u[5] = cmul(u[5], cmul(w4, w1));
-                    u[6] = cmul(u[6], cmul(w4, w2));
-                    u[7] = cmul(u[7], cmul(w4, w3));
+                    u[4] = cmul(w4, u[4]);
+                    u[5] = cmul(cmul(w4, w1), u[5]);
+                    u[6] = cmul(cmul(w4, w2), u[6]);
+                    u[7] = cmul(cmul(w4, w3), u[7]);
                 }
             }
         }
@@ -134,9 +145,10 @@ __device__ __forceinline__ void fft_pass(float2 (&x)[N / T], float2 *lds, const 
             for (int r = 0; r < R; r++) x[q + r * Q] = u[r];
         } else {
             // lpad(j + r*P) == lpad(j) + lpad(r*P): (j mod 32) + (r*P mod 32) never carries for power-of-two P
-            // (j = P*R*c + k with k < P), so the R scatters share one base register and use immediate offsets
-            const int j = (b - k) * R + k;
-            float2 *wp = lds + lpad(j);
+            // (j = P*R*c + k with k < P), so the R scatters share one base register and use immediate offsets.
+            // j itself splits into a per-pass base (wbase, from tid) plus a per-q constant that is a multiple of T.
+            const int cq = (P <= T) ? T * R * q : R * (T * q - (T * q) % P) + (T * q) % P;
+            float2 *wp = wbase + lpad(cq);
 #pragma unroll
             for (int r = 0; r < R; r++) wp[lpad(r * P)] = u[r];
         }

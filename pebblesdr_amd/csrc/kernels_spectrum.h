@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
     const float2 tw_lane = cis_cycles(-(double)(lane * q) / (double)BINS);  // W_bins^{lane q}
     const float2 *bq = btab + q * E;                                         // W_bins^{64 m q}, m < E (wave-uniform)
 
-    float pa[E];  // previous frame's linear amplitudes of bins ZP*(lane+64m)+q
+    float pa[E];  // previous frame's |X| (unscaled) of bins ZP*(lane+64m)+q
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float2 xn[EL];
     // prologue: park the first frame this group transforms (f0 - 1, or frame 0 at the call boundary)
     {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 const float2 xv = gp[((64 * m) / SL) * REGION + (64 * m) % SL];
-                v[m] = ZP == 1 ? xv : cmul(cmul(xv, tw_lane), bq[m]);
+                v[m] = ZP == 1 ? xv : cmul(bq[m], cmul(tw_lane, xv));  // constants first (see cmul)
             }
         }
         __syncthreads();  // A: every wave holds the frame in registers; regions may be overwritten
@@ -115,12 +116,13 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
             float *st = stage + ln;
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const float amp = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y) * sp.scale;
-                const float a = 0.5f * (amp + pa[m]);  // fft.cpp:379-381
+                // amplitude = |X| * scale, averaged with the previous frame's (fft.cpp:379-381): 0.5*scale*(|X| + |X'|).
+                // pa[] and the prev buffers carry the unscaled |X|; the factor moves into the log as a constant.
+                const float mag = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y);
                 // 20*log10(a) = 6.0206*log2(a); a == 0 gives -inf which the clip turns into -120 (db.h:24-26,44-48)
-                const float d = 6.02059991327962f * __builtin_amdgcn_logf(a);
+                const float d = fmaf(6.02059991327962f, __builtin_amdgcn_logf(mag + pa[m]), db_off);
                 st[64 * m] = fminf(fmaxf(d, -120.f), 0.f);  // for it == -1 nobody reads this slice
-                pa[m] = amp;
+                pa[m] = mag;
             }
             if (f == sp.n_frames - 1) {
                 float *pp = prev_out + (long long)s * BINS + ZP * ln + q;
@@ -224,6 +226,7 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
     float2 *my = lds[wave];
     float *stage = reinterpret_cast<float *>(my);
     float pa[E];
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     for (int it = -1; it < G; it++) {
         const long long f = f0 + it;
         const bool live = f < sp.n_frames;
@@ -242,10 +245,10 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
             float *st = stage + ln;
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const float amp = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y) * sp.scale;
-                const float av = 0.5f * (amp + pa[m]);
-                st[64 * m] = fminf(fmaxf(6.02059991327962f * __builtin_amdgcn_logf(av), -120.f), 0.f);
-                pa[m] = amp;
+                const float mag = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y);
+                const float d = fmaf(6.02059991327962f, __builtin_amdgcn_logf(mag + pa[m]), db_off);
+                st[64 * m] = fminf(fmaxf(d, -120.f), 0.f);
+                pa[m] = mag;
             }
             if (f == sp.n_frames - 1) {
                 float *pp = prev_out + (long long)s * kBigN + k1 + 32 * ln;
