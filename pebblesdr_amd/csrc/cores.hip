@@ -78,13 +78,25 @@ int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol)
 
 int make_twiddles(int n, float2 **d_tw)
 {
-    std::vector<float2> h(n);
-    for (int m = 0; m < n; m++) {
-        const double a = -design::kTwoPi * (double)m / (double)n;
-        h[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+    // per-pass tables in the layout fft_lds.h reads (fft_tw_off)
+    if (!(n == 2048 || n == 4096 || n == 8192)) return fail(PEBBLEGPU_E_UNSUPPORTED, "no FFT plan for %d points", n);
+    std::vector<float2> h((size_t)fft_tw_off(n, n));
+    int P = 1;
+    for (int pass = 0; pass < fft_passes(n); pass++) {
+        const int R = fft_radix(n, pass);
+        if (P > 1) {
+            float2 *t = h.data() + fft_tw_off(n, P);
+            for (int k = 0; k < P; k++)
+                for (int e = 0; e < 3; e++) {
+                    const long long idx = ((long long)k * (n / (P * R)) << e) % n;
+                    const double a = -design::kTwoPi * (double)idx / (double)n;
+                    t[e * P + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+                }
+        }
+        P *= R;
     }
-    PG_HIP(hipMalloc((void **)d_tw, sizeof(float2) * n));
-    PG_HIP(hipMemcpy(*d_tw, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    PG_HIP(hipMalloc((void **)d_tw, sizeof(float2) * h.size()));
+    PG_HIP(hipMemcpy(*d_tw, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -687,15 +699,6 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     PG_HIP(hipMemcpy(d_window, wf.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
     // btab[q][m] = exp(-2*pi*i*(64*m*q)/bins): the wave-uniform factor of the pruned-FFT pre-twiddle W_bins^{n q},
     // n = lane + 64 m (the per-lane factor W_bins^{lane q} is computed in the kernel)
-    if (big) {
-        std::vector<float2> w32(32);
-        for (int m = 0; m < 32; m++) {
-            const double a = -design::kTwoPi * (double)m / 32.0;
-            w32[m] = make_float2((float)std::cos(a), (float)std::sin(a));
-        }
-        PG_HIP(hipMalloc((void **)&d_w32, sizeof(float2) * 32));
-        PG_HIP(hipMemcpy(d_w32, w32.data(), sizeof(float2) * 32, hipMemcpyHostToDevice));
-    }
     const uint32_t zp = bins / nf;
     std::vector<float2> bt((size_t)zp * 32);
     for (uint32_t q = 0; q < zp; q++)
@@ -716,9 +719,9 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_w32, d_Y};
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y};
     for (void *q : p) if (q) (void)hipFree(q);
-    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_w32 = d_Y = nullptr;
+    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr;
     y_cap = 0;
 }
 int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out)
@@ -742,7 +745,7 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         sp.frames_per_group = (int)G;
         sp.scale = scale;
         sp.out_pitch = F * (long long)bins;
-        launch(k_big_cols, dim3((unsigned)(F * 8), S), dim3(256), s, d_in, (long long)in_pitch, d_Y, (const float *)d_window, (const float2 *)d_w32, (long long)F);
+        launch(k_big_cols, dim3((unsigned)(F * 8), S), dim3(256), s, d_in, (long long)in_pitch, d_Y, (const float *)d_window, (long long)F);
         launch(k_big_rows, dim3((unsigned)(cdiv(F, G) * 8), S), dim3(256), s, (const float2 *)d_Y, d_out, (const float2 *)d_tw_nf,
                (const float *)d_prev[parity], d_prev[parity ^ 1], sp);
         parity ^= 1;
@@ -752,6 +755,7 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
     const int groups = 4 / (int)(bins / nf);  // wave groups (frames in flight) per workgroup
     long long G = (F * (long long)S) / (1024 * groups);  // aim for ~1024 workgroups; each group recomputes one extra frame
     G = G < 1 ? 1 : (G > 16 ? 16 : G);
+    if (const char *e = getenv("PG_EXP_G")) G = atoll(e);
     sp.frames_per_group = (int)G;
     sp.scale = scale;
     sp.out_pitch = F * (long long)bins;

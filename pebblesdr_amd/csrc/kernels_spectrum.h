@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
     constexpr int XOFF = NF / 2;
     constexpr int REGION = (XOFF + SL > FftLds<NF>::kSlots) ? XOFF + SL : FftLds<NF>::kSlots;
     __shared__ float2 lds[4][REGION];
-    __shared__ float2 tw_lds[NF / 2];  // W_2048^m, m < 1024: every twiddle index the passes use stays below N/2
+    __shared__ float2 tw_lds[fft_tw_off(NF, NF)];  // per-pass twiddle tables (fft_lds.h), 7 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave / ZP, q = wave % ZP, s = blockIdx.y;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
     float2 *my = lds[wave];
     float *stage = reinterpret_cast<float *>(my);  // this wave's dB slice, [j] for bins ZP*j + q
 
-    for (int i = threadIdx.x; i < NF / 2; i += 256) tw_lds[i] = tw_nf[i];
+    for (int i = threadIdx.x; i < fft_tw_off(NF, NF); i += 256) tw_lds[i] = tw_nf[i];
 
     float win[EL];  // window values of the slice this wave loads: constant over frames
 #pragma unroll
@@ -114,16 +114,29 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
         } else if (xform) {
             fft_regs<NF, +1, 64>(v, my, tw_lds, ln);
             float *st = stage + ln;
+            // amplitude = |X| * scale, averaged with the previous frame's (fft.cpp:379-381): 0.5*scale*(|X| + |X'|).
+            // pa[] and the prev buffers carry the unscaled |X|; the factor moves into the log as a constant.
+            // 20*log10(a) = 6.0206*log2(a); a == 0 gives -inf which the clip turns into -120 (db.h:24-26,44-48).
+            // One operation at a time over all 32 bins: sqrt and log are long-latency, so the 32 independent
+            // instances of each have to be in flight together (a wave has nothing else to issue meanwhile).
+            float mag[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = v[m].x * v[m].x + v[m].y * v[m].y;
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_sqrtf(mag[m]);
+            sched_fence();
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                // amplitude = |X| * scale, averaged with the previous frame's (fft.cpp:379-381): 0.5*scale*(|X| + |X'|).
-                // pa[] and the prev buffers carry the unscaled |X|; the factor moves into the log as a constant.
-                const float mag = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y);
-                // 20*log10(a) = 6.0206*log2(a); a == 0 gives -inf which the clip turns into -120 (db.h:24-26,44-48)
-                const float d = fmaf(6.02059991327962f, __builtin_amdgcn_logf(mag + pa[m]), db_off);
-                st[64 * m] = fminf(fmaxf(d, -120.f), 0.f);  // for it == -1 nobody reads this slice
-                pa[m] = mag;
+                const float a = mag[m] + pa[m];
+                pa[m] = mag[m];
+                mag[m] = a;
             }
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_logf(mag[m]);
+            sched_fence();
+#pragma unroll
+            for (int m = 0; m < E; m++)
+                st[64 * m] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);  // for it == -1 nobody reads this slice
             if (f == sp.n_frames - 1) {
                 float *pp = prev_out + (long long)s * BINS + ZP * ln + q;
 #pragma unroll
@@ -171,27 +184,9 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int kBigN = 65536, kBigR = 32, kBigM = 2048;
 
-// 32-point DFT in registers as 8 x 4 (n1 = 4*na + nb): DFT8 over na, twiddle W32^{nb*ka}, DFT4 over nb.
-// in: u[n1]; out: X[ka + 8*kb] left in u[4*ka + kb]  (read through perm32)
-__device__ __forceinline__ constexpr int perm32(int k) { return 4 * (k & 7) + (k >> 3); }
-__device__ __forceinline__ void dft32(float2 *u, const float2 *__restrict__ w32)
-{
-#pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-        float2 t[8];
-#pragma unroll
-        for (int na = 0; na < 8; na++) t[na] = u[nb + 4 * na];
-        bfly8<+1>(t);
-#pragma unroll
-        for (int ka = 0; ka < 8; ka++) u[4 * ka + nb] = nb == 0 ? t[ka] : cmul(t[ka], w32[(nb * ka) & 31]);
-    }
-#pragma unroll
-    for (int ka = 0; ka < 8; ka++) bfly4<+1>(u + 4 * ka);  // over nb: u[4*ka + kb] = X[ka + 8*kb]
-}
-
 // grid (frames * 8, S), block 256.  Y layout: [stream][frame][k1][n2]
 static __global__ __launch_bounds__(256) void k_big_cols(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ Y,
-                                                         const float *__restrict__ window, const float2 *__restrict__ w32,
+                                                         const float *__restrict__ window,
                                                          long long n_frames)
 {
     const int s = blockIdx.y;
@@ -201,7 +196,7 @@ static __global__ __launch_bounds__(256) void k_big_cols(const float2 *__restric
     float2 u[kBigR];
 #pragma unroll
     for (int n1 = 0; n1 < kBigR; n1++) u[n1] = cscale(x[(long long)kBigM * n1], window[kBigM * n1 + n2]);
-    dft32(u, w32);
+    dft32(u);
     float2 *y = Y + ((long long)s * n_frames + f) * kBigN + n2;
 #pragma unroll
     for (int k1 = 0; k1 < kBigR; k1++) {
@@ -243,13 +238,23 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
             for (int m = 0; m < E; m++) v[m] = row[64 * m];
             fft_regs<kBigM, +1, 64>(v, my, tw_nf, ln);
             float *st = stage + ln;
+            float mag[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = v[m].x * v[m].x + v[m].y * v[m].y;
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_sqrtf(mag[m]);
+            sched_fence();
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const float mag = __builtin_amdgcn_sqrtf(v[m].x * v[m].x + v[m].y * v[m].y);
-                const float d = fmaf(6.02059991327962f, __builtin_amdgcn_logf(mag + pa[m]), db_off);
-                st[64 * m] = fminf(fmaxf(d, -120.f), 0.f);
-                pa[m] = mag;
+                const float a = mag[m] + pa[m];
+                pa[m] = mag[m];
+                mag[m] = a;
             }
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_logf(mag[m]);
+            sched_fence();
+#pragma unroll
+            for (int m = 0; m < E; m++) st[64 * m] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);
             if (f == sp.n_frames - 1) {
                 float *pp = prev_out + (long long)s * kBigN + k1 + 32 * ln;
 #pragma unroll

@@ -156,9 +156,9 @@ struct SpectrumCore {
     float *d_prev[2] = {nullptr, nullptr};
     float *d_window = nullptr;
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
-    // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): W32 table and the [S][F][32][2048] intermediate
+    // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): the [S][F][32][2048] intermediate
     bool big = false;
-    float2 *d_w32 = nullptr, *d_Y = nullptr;
+    float2 *d_Y = nullptr;
     size_t y_cap = 0;
     float scale = 0;
     int parity = 0;
