@@ -603,15 +603,29 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
     for (size_t i = 0; i < h.size(); i++) hf[i] = (float)h[i];
     PG_HIP(hipMalloc((void **)&d_taps, sizeof(float) * kMaxTaps));
     PG_HIP(hipMemcpy(d_taps, hf.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
-    // one fused kernel when both warm-ups fit its LDS budget (they do at every rate the WFM chain produces);
-    // otherwise the exact sequential multi-kernel path below
-    fused = warm_lp > 0 && warm_dn > 0 && warm_lp * kSub <= kWfmMaxWarm && warm_dn * kSub <= kWfmMaxWarm;
-    if (fused) {
-        for (int i = 0; i < 2; i++) {
-            PG_HIP(hipMalloc((void **)&d_state[i], sizeof(WfmState) * C));
-            PG_HIP(hipMemset(d_state[i], 0, sizeof(WfmState) * C));
+    // One kernel with no carried state when the cascades decay fast enough to be folded into FIRs (they do at every rate
+    // the WFM chain produces: pole radii <= ~0.97); otherwise the exact sequential multi-kernel path below.
+    {
+        std::vector<double> hl(1, 1.0), ha;
+        bool ok = true;
+        if (lp_on) ok = design::cascade_impulse(std::vector<double>(), nullptr, std::vector<design::Biquad>(1, l), 1e-11, kWfmLpMax, hl);
+        if (ok) ok = design::cascade_impulse(h, &da, std::vector<design::Biquad>(1, br), 1e-11, kWfmIrMax, ha);
+        fused = ok && wfm_fir_lds_bytes((int)((ha.size() + 15) & ~(size_t)15), (int)hl.size()) <= 64 * 1024;
+        if (fused) {
+            L4 = (int)((ha.size() + 15) & ~(size_t)15);
+            Llp = (int)hl.size();
+            ha.resize((size_t)L4 + 16, 0.0);  // the kernel fetches its taps one chunk of 16 ahead
+            std::vector<float> hlf(hl.begin(), hl.end());
+            PG_HIP(hipMalloc((void **)&d_h, sizeof(double) * (L4 + 16)));
+            PG_HIP(hipMemcpy(d_h, ha.data(), sizeof(double) * (L4 + 16), hipMemcpyHostToDevice));
+            PG_HIP(hipMalloc((void **)&d_hlp, sizeof(float) * Llp));
+            PG_HIP(hipMemcpy(d_hlp, hlf.data(), sizeof(float) * Llp, hipMemcpyHostToDevice));
+            for (int i = 0; i < 2; i++) {
+                PG_HIP(hipMalloc((void **)&d_xtail[i], sizeof(float2) * (size_t)(L4 + Llp) * C));
+                PG_HIP(hipMemset(d_xtail[i], 0, sizeof(float2) * (size_t)(L4 + Llp) * C));
+            }
+            return 0;
         }
-        return 0;
     }
     if (int rc = a.alloc((int)C, 2, max_n)) return rc;
     if (int rc = b.alloc((int)C, kMaxTaps, max_n)) return rc;
@@ -627,31 +641,35 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 void WfmCore::release()
 {
     a.release(); b.release(); c.release();
-    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_state[0], d_state[1]};
+    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_h, d_hlp, d_xtail[0], d_xtail[1]};
     for (void *q : p) if (q) (void)hipFree(q);
     d_taps = nullptr;
     d_lp_state[0] = d_lp_state[1] = d_dn_state[0] = d_dn_state[1] = nullptr;
-    d_state[0] = d_state[1] = nullptr;
+    d_h = nullptr; d_hlp = nullptr; d_xtail[0] = d_xtail[1] = nullptr;
 }
 int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
 {
     if (n < kMaxTaps) return fail(PEBBLEGPU_E_SIZE, "WFM demod needs at least %d samples per call", kMaxTaps);
     last_n = n;
     if (fused) {
-        WfmParams wp;
+        WfmFirParams wp;
         memset(&wp, 0, sizeof(wp));
-        wp.lp = lp.sec[0];
-        wp.dn[0] = dn.sec[0];
-        wp.dn[1] = dn.sec[1];
-        wp.lp_on = lp_on ? 1 : 0;
-        wp.ntaps = ntaps;
-        wp.warm_lp = warm_lp * kSub;
-        wp.warm_dn = warm_dn * kSub;
+        wp.L4 = L4;
+        wp.Llp = Llp;
         wp.gain = 0.25f;  // FMDEMOD_GAIN, demod_wfm.cpp:51
-        launch(k_wfm_mono, dim3(cdiv(n, kSub), C), dim3(256), s, in, in_pitch, out, out_pitch, n, wp, (const float *)d_taps,
-               (const WfmState *)d_state[parity], d_state[parity ^ 1]);
-        parity ^= 1;
+        const long long Lx = (long long)L4 + Llp;
+        launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(256), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
+                   out, out_pitch, n, wp, (const double *)d_h, (const float *)d_hlp);
         PG_HIP(hipGetLastError());
+        // next call's history = the last Lx samples of (old history | this call's input), into the other buffer
+        float2 *nt = d_xtail[parity ^ 1];
+        if (n >= Lx) {
+            PG_HIP(hipMemcpy2DAsync(nt, sizeof(float2) * Lx, in + (n - Lx), sizeof(float2) * in_pitch, sizeof(float2) * Lx, C, hipMemcpyDeviceToDevice, s));
+        } else {
+            PG_HIP(hipMemcpy2DAsync(nt, sizeof(float2) * Lx, d_xtail[parity] + n, sizeof(float2) * Lx, sizeof(float2) * (Lx - n), C, hipMemcpyDeviceToDevice, s));
+            PG_HIP(hipMemcpy2DAsync(nt + (Lx - n), sizeof(float2) * Lx, in, sizeof(float2) * in_pitch, sizeof(float2) * n, C, hipMemcpyDeviceToDevice, s));
+        }
+        parity ^= 1;
         return 0;
     }
     if (n > a.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
@@ -755,7 +773,6 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
     const int groups = 4 / (int)(bins / nf);  // wave groups (frames in flight) per workgroup
     long long G = (F * (long long)S) / (1024 * groups);  // aim for ~1024 workgroups; each group recomputes one extra frame
     G = G < 1 ? 1 : (G > 16 ? 16 : G);
-    if (const char *e = getenv("PG_EXP_G")) G = atoll(e);
     sp.frames_per_group = (int)G;
     sp.scale = scale;
     sp.out_pitch = F * (long long)bins;

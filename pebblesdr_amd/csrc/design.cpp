@@ -185,5 +185,42 @@ double spectral_radius(const M2 &x)
     return std::fmax(std::fabs(tr / 2 + r), std::fabs(tr / 2 - r));
 }
 
+bool cascade_impulse(const std::vector<double> &fir_prefix, const double *one_pole_avg_a, const std::vector<Biquad> &biquads, double tol,
+                     int max_len, std::vector<double> &h)
+{
+    const int n = max_len + 4096;  // run well past max_len so the tail sum is known
+    std::vector<double> y((size_t)n, 0.0);
+    if (fir_prefix.empty()) y[0] = 1.0;
+    else for (size_t i = 0; i < fir_prefix.size() && i < (size_t)n; i++) y[i] = fir_prefix[i];
+    if (one_pole_avg_a) {
+        const double a = *one_pole_avg_a;
+        double s0 = 0;
+        for (int i = 0; i < n; i++) { s0 = (1.0 - a) * s0 + a * y[i]; y[i] = s0 * 2.0; }
+    }
+    for (const Biquad &q : biquads) {
+        double w1 = 0, w2 = 0;
+        for (int i = 0; i < n; i++) {
+            const double w0 = y[i] - q.a1 * w1 - q.a2 * w2;
+            y[i] = q.b0 * w0 + q.b1 * w1 + q.b2 * w2;
+            w2 = w1;
+            w1 = w0;
+        }
+    }
+    double total = 0;
+    for (double v : y) total += std::fabs(v);
+    if (!(total > 0)) return false;
+    // residual beyond the simulated window: bounded by the geometric decay of the last stretch
+    double tail = 0;
+    for (int i = n - 1; i >= max_len; i--) tail += std::fabs(y[i]);
+    double last = 0;
+    for (int i = n - 256; i < n; i++) last += std::fabs(y[i]);
+    if (last > tol * total * 1e-3) return false;  // still ringing at the end of the window: slow poles
+    int len = max_len;
+    if (tail > tol * total) return false;
+    while (len > 1 && tail + std::fabs(y[len - 1]) <= tol * total) { tail += std::fabs(y[len - 1]); len--; }
+    h.assign(y.begin(), y.begin() + len);
+    return true;
+}
+
 }  // namespace design
 }  // namespace pg

@@ -49,6 +49,13 @@ Biquad biquad_notch(double f0, double q, double fs);
 // WindowFunction BLACKMANHARRIS, pebblelib/windowfunction.cpp:214-235; returns coherentGain = sum/N
 double blackman_harris(uint32_t n, std::vector<double> &w);
 
+// Impulse response of  [optional FIR prefix] -> [one-pole average: s = (1-a) s + a u, y = 2 s] -> [biquads DF2 ...],
+// run in fp64 and truncated where the remaining absolute tail sum drops below tol * (total absolute sum).  Used to turn
+// fast-decaying IIR cascades into one FIR (every output then depends only on input history: no carried filter state,
+// fully parallel).  Returns false if the response is still above tol after max_len samples (slow poles).
+bool cascade_impulse(const std::vector<double> &fir_prefix, const double *one_pole_avg_a, const std::vector<Biquad> &biquads, double tol,
+                     int max_len, std::vector<double> &h);
+
 // 2x2 real matrix helpers for the chunked recurrence scans (state transition powers)
 struct M2 { double a, b, c, d; };
 M2 m2_mul(const M2 &x, const M2 &y);

@@ -142,154 +142,128 @@ static __global__ __launch_bounds__(64) void k_iir_scan(const float2 *__restrict
     }
 }
 
-// Demod_WFM::processDataMono (application/demod/demod_wfm.cpp:207-232) in ONE kernel, one wave per 512 output samples:
+// Demod_WFM::processDataMono (application/demod/demod_wfm.cpp:207-232) in ONE kernel with NO carried filter state:
 //   biquad low-pass on I and Q (if rate >= 150 kHz)  ->  0.25*atan2 discriminator  ->  75-tap CFir  ->  de-emphasis  ->  19 kHz notch
-// The two recurrences are wave scans (scan_sub).  A workgroup that does not start at the call boundary rebuilds their
-// state by running the filters over a warm-up stretch from zero state (host sizes it so pole^samples < 1e-13):
-//   notch/de-emphasis warm-up Wd, then 74 samples of FIR look-back + 1 of discriminator look-back, then the low-pass
-//   warm-up Wl  ->  up to Wd + Wl + 512 + 75 input samples per 512 outputs, all kept in LDS.
-// At the call boundary the exact state of the previous call is used instead: recurrence states, the last low-passed
-// sample and the last 74 discriminator outputs (ping-pong buffers: block 0 reads while the last block writes).
-// grid (ceil(n/512), C), block 256 (wave 0 scans I and later the audio, wave 1 scans Q; all four do the rest).
-struct WfmParams {
-    ScanSection lp;       // biquad low-pass (applied to I and Q independently)
-    ScanSection dn[2];    // de-emphasis, notch
-    int lp_on, ntaps;     // FIR length (<= 75)
-    int warm_lp, warm_dn; // warm-up lengths in samples (multiples of kSub)
-    float gain;           // FMDEMOD_GAIN
+// The recurrences of this path have fast poles (radius <= ~0.97 at every WFM rate), so the host folds each cascade into
+// its truncated impulse response (design::cascade_impulse, fp64, tail below 1e-11 of the total): `hlp` for the low-pass
+// and ONE combined response `h` for CFir * de-emphasis * notch.  Every output then depends only on input history --
+// the previous call's last Lx input samples (`xtail`) -- and all outputs are computed independently: no scans, no
+// warm-up runs, no sequential carries.  (The scan kernels above remain for slow poles: AM's DC block, other rates.)
+//
+// One workgroup per kWfmOutB = 1024 outputs.  x -> LDS; low-pass (fp32, Llp taps) -> LDS; discriminator -> LDS as
+// fp64 in blocks of 4 (+2 pad: 48-byte stride keeps the 16-byte block reads of 4-output work-items conflict-free);
+// audio FIR: each work-item owns 4 consecutive outputs, slides a two-block window through the history and takes the
+// taps from scalar registers -- 16 fp64 FMAs per 4 taps against one 32-byte LDS read.
+constexpr int kWfmOutB = 1024;    // outputs per workgroup
+constexpr int kWfmIrMax = 1536;   // longest combined audio response (taps, multiple of 16) that fits the LDS budget
+constexpr int kWfmLpMax = 64;     // longest low-pass response
+
+struct WfmFirParams {
+    int L4;        // combined audio response length, zero-padded to a multiple of 16
+    int Llp;       // low-pass response length (1 with tap 1.0 when the low-pass is off)
+    float gain;    // FMDEMOD_GAIN
     int pad_;
 };
-struct WfmState {         // per channel
-    double lp[2][2];      // [component][2]
-    double dn[2][2];      // [section][2]
-    float2 lp_last;       // last low-passed sample of the previous call (discriminator look-back)
-    float dtail[kMaxTaps];  // last ntaps-1 discriminator outputs, oldest first (FIR look-back)
-    float pad_[2];
-};
-
-constexpr int kWfmMaxWarm = 4 * kSub;  // per recurrence
-
-static __global__ __launch_bounds__(256) void k_wfm_mono(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ out,
-                                                         long long out_pitch, long long n, WfmParams wp,
-                                                         const float *__restrict__ taps, const WfmState *__restrict__ st_in,
-                                                         WfmState *__restrict__ st_out)
+__host__ __device__ inline size_t wfm_fir_lds_bytes(int L4, int Llp)
 {
-    constexpr int kPad = kSub + kSub / kSeg + 1;
-    constexpr int kLp = kWfmMaxWarm + kSub + kMaxTaps;   // low-passed samples a block may keep
-    __shared__ float re[kPad], im[kPad];
-    __shared__ float2 lpbuf[kLp];
-    __shared__ float dbuf[kLp + 8 * 256];                 // + slack so the register-blocked FIR may read past the end
-    __shared__ float fbuf[kWfmMaxWarm + kSub];
-    __shared__ float ht[kMaxTaps];
-    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.y;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = wp.ntaps;
+    const size_t nd = (size_t)kWfmOutB + L4, nl = nd + 1, nx = nl + Llp - 1;
+    return nx * sizeof(float2) + nl * sizeof(float2) + (nd / 4) * 6 * sizeof(double);
+}
+
+// xtail: [channel][L4 + Llp] input samples preceding in[0] (zeros before the first call)
+static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ xtail,
+                                                        float2 *__restrict__ out, long long out_pitch, long long n, WfmFirParams wp,
+                                                        const double *__restrict__ h, const float *__restrict__ hlp)
+{
+    HIP_DYNAMIC_SHARED(double, dyn)
+    const int L4 = wp.L4, Llp = wp.Llp;
+    const int ND = kWfmOutB + L4, NL = ND + 1, NX = NL + Llp - 1, Lx = L4 + Llp;
+    double *db = dyn;                                                   // (ND/4) blocks of 6 doubles
+    float2 *lpb = reinterpret_cast<float2 *>(db + (ND / 4) * 6);         // NL
+    float2 *xs = lpb + NL;                                               // NX
+    __shared__ float hl[kWfmLpMax];
+    const int tid = threadIdx.x, c = blockIdx.y;
+    const long long s = (long long)blockIdx.x * kWfmOutB;
     const float2 *x = in + (long long)c * in_pitch;
-    const WfmState *si = st_in + c;
-    const long long s = (long long)blockIdx.x * kSub;                    // first output of this block
-    const long long e = (s + kSub) < n ? (s + kSub) : n;                 // one past its last output
-    const bool last_block = e == n;
-    if (tid < kMaxTaps) ht[tid] = tid < T ? taps[tid] : 0.f;
-
-    long long ds = s - wp.warm_dn;                                       // where the de-emphasis/notch run starts
-    const bool dn_exact = ds <= 0;
-    if (ds < 0) ds = 0;
-    const long long d0 = ds - (T - 1);                                   // first discriminator sample the FIR reads (may be < 0)
-    long long lk = d0 - 1;                                               // first low-passed sample kept (discriminator look-back)
-    if (lk < 0) lk = 0;
-    long long ls = lk - wp.warm_lp;                                      // where the low-pass run starts
-    const bool lp_exact = ls <= 0 || !wp.lp_on;
-    if (ls < 0 || !wp.lp_on) ls = wp.lp_on ? 0 : lk;
-
-    // ---- 1. low-pass over [ls, e), keeping [lk, e) in lpbuf.  Wave 0 scans I, wave 1 scans Q. ----
-    double q0 = 0, q1 = 0;  // biquad state of this wave's component
-    if (lp_exact && wp.lp_on && wave < 2) { q0 = si->lp[wave][0]; q1 = si->lp[wave][1]; }
-    for (long long off = ls; off < e; off += kSub) {
-        const int nv = (int)((e - off) < kSub ? (e - off) : kSub);
-        for (int j = tid; j < nv; j += 256) {
-            const float2 v = x[off + j];
-            re[spad(j)] = v.x;
-            im[spad(j)] = v.y;
-        }
-        __syncthreads();
-        if (wp.lp_on) {
-            if (wave == 0) scan_sub(wp.lp, re, nv, q0, q1, lane);
-            else if (wave == 1) scan_sub(wp.lp, im, nv, q0, q1, lane);
-        }
-        __syncthreads();
-        for (int j = tid; j < nv; j += 256) {
-            const long long idx = off + j;
-            if (idx >= lk) lpbuf[idx - lk] = make_float2(re[spad(j)], im[spad(j)]);
-        }
-        __syncthreads();
-    }
-    // ---- 2. discriminator over [max(d0,0), e); older samples come from the previous call's tail ----
-    const int nd = (int)(e - d0);                                        // dbuf[i] <-> discriminator sample d0 + i
-    for (int i = tid; i < nd; i += 256) {
-        const long long idx = d0 + i;
-        float v;
-        if (idx < 0) {
-            v = si->dtail[(T - 1) + idx];
-        } else {
-            const float2 c0 = lpbuf[idx - lk];
-            const float2 c1 = idx == 0 ? si->lp_last : lpbuf[idx - 1 - lk];
-            v = wp.gain * atan2f(c1.x * c0.y - c0.x * c1.y, c1.x * c0.x + c1.y * c0.y);  // demod_wfm.cpp:217
-        }
-        dbuf[i] = v;
+    const float2 *xt = xtail + (long long)c * Lx;
+    if (tid < kWfmLpMax) hl[tid] = tid < Llp ? hlp[tid] : 0.f;
+    // ---- 1. input samples x0 .. x0+NX-1, x0 = s - L4 - Llp (history from the tail, nothing past n) ----
+    const long long x0 = s - Lx;
+    for (int j = tid; j < NX; j += 256) {
+        const long long g = x0 + j;
+        float2 v = make_float2(0.f, 0.f);
+        if (g < 0) v = xt[Lx + g];
+        else if (g < n) v = x[g];
+        xs[j] = v;
     }
     __syncthreads();
-    // ---- 3. CFir over [ds, e): y[i] = sum_p d[i - (T-1) + p] * h[p]; 10 outputs per work-item in flight ----
-    const int nf = (int)(e - ds);
-    {
-        constexpr int RB = (kWfmMaxWarm + kSub) / 256;  // 10
-        float acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; r++) acc[r] = 0.f;
-        const float *dp = dbuf + tid;
-        for (int p = 0; p < T; p++) {
-            const float h = ht[p];
-#pragma unroll
-            for (int r = 0; r < RB; r++) acc[r] = fmaf(dp[p + 256 * r], h, acc[r]);
+    // ---- 2. low-pass: lpb[k] = sum_m hlp[m] * x[(s - L4 - 1 + k) - m]; taps from LDS (a per-iteration scalar load
+    //         would expose its latency every tap) ----
+    for (int k = tid; k < NL; k += 256) {
+        const float2 *xp = xs + k + Llp - 1;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int m = 0; m < Llp; m++) {
+            const float2 v = xp[-m];
+            const float t = hl[m];
+            acc.x = fmaf(t, v.x, acc.x);
+            acc.y = fmaf(t, v.y, acc.y);
         }
-#pragma unroll
-        for (int r = 0; r < RB; r++)
-            if (tid + 256 * r < nf) fbuf[tid + 256 * r] = acc[r];
+        lpb[k] = acc;
     }
     __syncthreads();
-    // ---- 4. de-emphasis + notch over [ds, e) on wave 0, emitting [s, e) ----
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-    if (dn_exact) { a0 = si->dn[0][0]; a1 = si->dn[0][1]; b0 = si->dn[1][0]; b1 = si->dn[1][1]; }
-    float2 *y = out + (long long)c * out_pitch;
-    for (long long off = ds; off < e; off += kSub) {
-        const int nv = (int)((e - off) < kSub ? (e - off) : kSub);
-        for (int j = tid; j < nv; j += 256) re[spad(j)] = fbuf[off - ds + j];
-        __syncthreads();
-        if (wave == 0) {
-            scan_sub(wp.dn[0], re, nv, a0, a1, lane);
-            scan_sub(wp.dn[1], re, nv, b0, b1, lane);
-        }
-        __syncthreads();
-        if (off + nv > s) {
-            for (int j = tid; j < nv; j += 256) {
-                const long long idx = off + j;
-                if (idx >= s) {
-                    const float v = re[spad(j)];
-                    y[idx] = make_float2(v, v);
-                }
+    // ---- 3. discriminator d[s - L4 + i], i < ND (demod_wfm.cpp:217), stored fp64 in padded blocks of 4 ----
+    for (int i = tid; i < ND; i += 256) {
+        const float2 c0 = lpb[i + 1], c1 = lpb[i];
+        const float v = wp.gain * atan2f(c1.x * c0.y - c0.x * c1.y, c1.x * c0.x + c1.y * c0.y);
+        db[(i >> 2) * 6 + (i & 3)] = (double)v;
+    }
+    __syncthreads();
+    // ---- 4. y[s + 4 tid + r] = sum_p h[p] * d[s + 4 tid + r - p] ----
+    //         Taps are fetched 16 at a time, one chunk (64 FMAs per output row) ahead of their use, with VECTOR loads of
+    //         a lane-invariant address: scalar loads share the LDS wait counter and return out of order, which would
+    //         force a full wait at every LDS read.  The next history block is read from LDS one group ahead.
+    const double *blk = db + (tid + (L4 >> 2)) * 6;
+    double cur[4], nxt[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) { cur[r] = blk[r]; nxt[r] = blk[r - 6]; }
+    int vz = 0;
+    opaque(vz);  // a zero the compiler must treat as per-lane: keeps the tap loads on the vector memory path
+    const double *hv = h + vz;
+    double hn[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) hn[u] = hv[u];
+    for (int p0 = 0; p0 < L4; p0 += 16) {  // L4 is a multiple of 16; h carries 16 zeros past it
+        double ht[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) ht[u] = hn[u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) hn[u] = hv[p0 + 16 + u];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            blk -= 6;
+            double prev[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) prev[r] = nxt[r];
+            if (p0 + 4 * g + 4 < L4) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) nxt[r] = blk[r - 6];
             }
+            const double h0 = ht[4 * g], h1 = ht[4 * g + 1], h2 = ht[4 * g + 2], h3 = ht[4 * g + 3];
+            acc[0] = fma(h0, cur[0], acc[0]); acc[1] = fma(h0, cur[1], acc[1]); acc[2] = fma(h0, cur[2], acc[2]); acc[3] = fma(h0, cur[3], acc[3]);
+            acc[0] = fma(h1, prev[3], acc[0]); acc[1] = fma(h1, cur[0], acc[1]); acc[2] = fma(h1, cur[1], acc[2]); acc[3] = fma(h1, cur[2], acc[3]);
+            acc[0] = fma(h2, prev[2], acc[0]); acc[1] = fma(h2, prev[3], acc[1]); acc[2] = fma(h2, cur[0], acc[2]); acc[3] = fma(h2, cur[1], acc[3]);
+            acc[0] = fma(h3, prev[1], acc[0]); acc[1] = fma(h3, prev[2], acc[1]); acc[2] = fma(h3, prev[3], acc[2]); acc[3] = fma(h3, cur[0], acc[3]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) cur[r] = prev[r];
         }
-        __syncthreads();
     }
-    // ---- 5. the block that reaches the end of the call leaves the exact state for the next one ----
-    if (last_block) {
-        WfmState *so = st_out + c;
-        if (lane == 0 && wave < 2) { so->lp[wave][0] = q0; so->lp[wave][1] = q1; }
-        if (tid == 0) {
-            so->dn[0][0] = a0; so->dn[0][1] = a1; so->dn[1][0] = b0; so->dn[1][1] = b1;
-            so->lp_last = lpbuf[(n - 1) - lk];
+    float2 *y = out + (long long)c * out_pitch + s + 4 * tid;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (s + 4 * tid + r < n) {
+            const float v = (float)acc[r];
+            y[r] = make_float2(v, v);  // mono: left = right (demod_wfm.cpp:229-230)
         }
-        for (int j = tid; j < T - 1; j += 256) so->dtail[j] = dbuf[(n - (T - 1) + j) - d0];
-    }
 }
 
 // The PLL demodulators -- Demod_NFM::processBlockNCO (application/demod/demod_nfm.cpp:225-257) and Demod_SAM::pll /

@@ -141,8 +141,11 @@ struct WfmCore {
     ScanParams<2> dn;
     int warm_lp = -1, warm_dn = -1, parity = 0;
     double *d_lp_state[2] = {nullptr, nullptr}, *d_dn_state[2] = {nullptr, nullptr};
-    bool fused = false;             // single-kernel path (k_wfm_mono); else the multi-kernel sequential fallback
-    struct WfmState *d_state[2] = {nullptr, nullptr};
+    bool fused = false;             // single-kernel FIR-ised path (k_wfm_fir); else the multi-kernel sequential fallback
+    int L4 = 0, Llp = 1;            // fused: combined audio response (padded to 16) and low-pass response lengths
+    double *d_h = nullptr;          // [L4]
+    float *d_hlp = nullptr;         // [Llp]
+    float2 *d_xtail[2] = {nullptr, nullptr};  // [C][L4 + Llp] input history, ping-pong
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);

@@ -253,6 +253,9 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipEmuEvent{0}; return 0; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new hipEmuEvent{0}; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = 0; return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
