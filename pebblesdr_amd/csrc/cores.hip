@@ -615,9 +615,9 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
             L4 = (int)((ha.size() + 15) & ~(size_t)15);
             Llp = (int)hl.size();
             ha.resize((size_t)L4 + 16, 0.0);  // the kernel fetches its taps one chunk of 16 ahead
-            std::vector<float> hlf(hl.begin(), hl.end());
-            PG_HIP(hipMalloc((void **)&d_h, sizeof(double) * (L4 + 16)));
-            PG_HIP(hipMemcpy(d_h, ha.data(), sizeof(double) * (L4 + 16), hipMemcpyHostToDevice));
+            std::vector<float> hlf(hl.begin(), hl.end()), haf(ha.begin(), ha.end());
+            PG_HIP(hipMalloc((void **)&d_h, sizeof(float) * (L4 + 16)));
+            PG_HIP(hipMemcpy(d_h, haf.data(), sizeof(float) * (L4 + 16), hipMemcpyHostToDevice));
             PG_HIP(hipMalloc((void **)&d_hlp, sizeof(float) * Llp));
             PG_HIP(hipMemcpy(d_hlp, hlf.data(), sizeof(float) * Llp, hipMemcpyHostToDevice));
             for (int i = 0; i < 2; i++) {
@@ -659,7 +659,7 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         wp.gain = 0.25f;  // FMDEMOD_GAIN, demod_wfm.cpp:51
         const long long Lx = (long long)L4 + Llp;
         launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(256), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
-                   out, out_pitch, n, wp, (const double *)d_h, (const float *)d_hlp);
+                   out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp);
         PG_HIP(hipGetLastError());
         // next call's history = the last Lx samples of (old history | this call's input), into the other buffer
         float2 *nt = d_xtail[parity ^ 1];

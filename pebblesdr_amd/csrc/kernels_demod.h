@@ -150,10 +150,12 @@ static __global__ __launch_bounds__(64) void k_iir_scan(const float2 *__restrict
 // the previous call's last Lx input samples (`xtail`) -- and all outputs are computed independently: no scans, no
 // warm-up runs, no sequential carries.  (The scan kernels above remain for slow poles: AM's DC block, other rates.)
 //
-// One workgroup per kWfmOutB = 1024 outputs.  x -> LDS; low-pass (fp32, Llp taps) -> LDS; discriminator -> LDS as
-// fp64 in blocks of 4 (+2 pad: 48-byte stride keeps the 16-byte block reads of 4-output work-items conflict-free);
-// audio FIR: each work-item owns 4 consecutive outputs, slides a two-block window through the history and takes the
-// taps from scalar registers -- 16 fp64 FMAs per 4 taps against one 32-byte LDS read.
+// One workgroup per kWfmOutB = 1024 outputs.  x -> LDS (one pad slot per 8 samples); low-pass (fp32, Llp taps): each
+// work-item owns 8 consecutive outputs and slides a register window over the padded samples -> LDS; discriminator ->
+// LDS as fp32 in blocks of 4; audio FIR: each work-item owns 4 consecutive outputs, slides a two-block window through
+// the history (one 16-byte LDS read per 4 taps against 16 FMAs), multiplies in fp32 and folds every 16-tap partial
+// sum into an fp64 accumulator (fp64 FMA runs at a fraction of the fp32 rate here; the fold keeps the rounding of a
+// 600..1500-tap sum at the 1e-7 level).
 constexpr int kWfmOutB = 1024;    // outputs per workgroup
 constexpr int kWfmIrMax = 1536;   // longest combined audio response (taps, multiple of 16) that fits the LDS budget
 constexpr int kWfmLpMax = 64;     // longest low-pass response
@@ -166,21 +168,21 @@ struct WfmFirParams {
 };
 __host__ __device__ inline size_t wfm_fir_lds_bytes(int L4, int Llp)
 {
-    const size_t nd = (size_t)kWfmOutB + L4, nl = nd + 1, nx = nl + Llp - 1;
-    return nx * sizeof(float2) + nl * sizeof(float2) + (nd / 4) * 6 * sizeof(double);
+    const size_t nd = (size_t)kWfmOutB + L4, nl = (nd + 1 + 7) & ~(size_t)7, nx = nl + Llp - 1;
+    return (nx + nx / 8 + 1) * sizeof(float2) + (nl + 1) * sizeof(float2) + nd * sizeof(float);
 }
 
 // xtail: [channel][L4 + Llp] input samples preceding in[0] (zeros before the first call)
 static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ xtail,
                                                         float2 *__restrict__ out, long long out_pitch, long long n, WfmFirParams wp,
-                                                        const double *__restrict__ h, const float *__restrict__ hlp)
+                                                        const float *__restrict__ h, const float *__restrict__ hlp)
 {
-    HIP_DYNAMIC_SHARED(double, dyn)
+    HIP_DYNAMIC_SHARED(float2, dyn)
     const int L4 = wp.L4, Llp = wp.Llp;
-    const int ND = kWfmOutB + L4, NL = ND + 1, NX = NL + Llp - 1, Lx = L4 + Llp;
-    double *db = dyn;                                                   // (ND/4) blocks of 6 doubles
-    float2 *lpb = reinterpret_cast<float2 *>(db + (ND / 4) * 6);         // NL
-    float2 *xs = lpb + NL;                                               // NX
+    const int ND = kWfmOutB + L4, NL = (ND + 1 + 7) & ~7, NX = NL + Llp - 1, Lx = L4 + Llp;
+    float2 *xs = dyn;                                                    // NX samples, position j + j/8
+    float2 *lpb = xs + (NX + NX / 8 + 1);                                // NL (+1)
+    float *db = reinterpret_cast<float *>(lpb + NL + 1);                 // ND
     __shared__ float hl[kWfmLpMax];
     const int tid = threadIdx.x, c = blockIdx.y;
     const long long s = (long long)blockIdx.x * kWfmOutB;
@@ -194,68 +196,74 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
         float2 v = make_float2(0.f, 0.f);
         if (g < 0) v = xt[Lx + g];
         else if (g < n) v = x[g];
-        xs[j] = v;
+        xs[j + (j >> 3)] = v;
     }
     __syncthreads();
-    // ---- 2. low-pass: lpb[k] = sum_m hlp[m] * x[(s - L4 - 1 + k) - m]; taps from LDS (a per-iteration scalar load
-    //         would expose its latency every tap) ----
-    for (int k = tid; k < NL; k += 256) {
-        const float2 *xp = xs + k + Llp - 1;
-        float2 acc = make_float2(0.f, 0.f);
-        for (int m = 0; m < Llp; m++) {
-            const float2 v = xp[-m];
-            const float t = hl[m];
-            acc.x = fmaf(t, v.x, acc.x);
-            acc.y = fmaf(t, v.y, acc.y);
+    // ---- 2. low-pass: lpb[k] = sum_m hlp[m] * xs[k + Llp - 1 - m], k < NL.  Work-item: outputs 8a .. 8a+7; with the
+    //         pad its 9-slot stride spreads a wave's 8-byte reads over all banks. ----
+    for (int a8 = tid * 8; a8 < NL; a8 += 256 * 8) {
+        float2 w[8], acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            acc[r] = make_float2(0.f, 0.f);
+            const int j = a8 + r + Llp - 1;
+            w[r] = xs[j + (j >> 3)];  // tap 0 operands: w[r] = x for output a8 + r
         }
-        lpb[k] = acc;
+        for (int m = 0; m < Llp; m++) {
+            const float t = hl[m];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                acc[r].x = fmaf(t, w[r].x, acc[r].x);
+                acc[r].y = fmaf(t, w[r].y, acc[r].y);
+            }
+#pragma unroll
+            for (int r = 7; r > 0; r--) w[r] = w[r - 1];
+            const int j = a8 + Llp - 2 - m;  // next tap's operand of output a8 (may run below 0 on the last turn)
+            w[0] = j >= 0 ? xs[j + (j >> 3)] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) lpb[a8 + r] = acc[r];
     }
     __syncthreads();
-    // ---- 3. discriminator d[s - L4 + i], i < ND (demod_wfm.cpp:217), stored fp64 in padded blocks of 4 ----
+    // ---- 3. discriminator d[s - L4 + i], i < ND (demod_wfm.cpp:217) ----
     for (int i = tid; i < ND; i += 256) {
         const float2 c0 = lpb[i + 1], c1 = lpb[i];
-        const float v = wp.gain * atan2f(c1.x * c0.y - c0.x * c1.y, c1.x * c0.x + c1.y * c0.y);
-        db[(i >> 2) * 6 + (i & 3)] = (double)v;
+        db[i] = wp.gain * atan2f(c1.x * c0.y - c0.x * c1.y, c1.x * c0.x + c1.y * c0.y);
     }
     __syncthreads();
     // ---- 4. y[s + 4 tid + r] = sum_p h[p] * d[s + 4 tid + r - p] ----
-    //         Taps are fetched 16 at a time, one chunk (64 FMAs per output row) ahead of their use, with VECTOR loads of
+    //         Taps are fetched 16 at a time, one chunk (64 FMAs per work-item) ahead of their use, with VECTOR loads of
     //         a lane-invariant address: scalar loads share the LDS wait counter and return out of order, which would
     //         force a full wait at every LDS read.  The next history block is read from LDS one group ahead.
-    const double *blk = db + (tid + (L4 >> 2)) * 6;
-    double cur[4], nxt[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; r++) { cur[r] = blk[r]; nxt[r] = blk[r - 6]; }
+    const float4 *blk = reinterpret_cast<const float4 *>(db) + tid + (L4 >> 2);
+    float4 cur = blk[0], nxt = blk[-1];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     int vz = 0;
     opaque(vz);  // a zero the compiler must treat as per-lane: keeps the tap loads on the vector memory path
-    const double *hv = h + vz;
-    double hn[16];
+    const float *hv = h + vz;
+    float hn[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) hn[u] = hv[u];
     for (int p0 = 0; p0 < L4; p0 += 16) {  // L4 is a multiple of 16; h carries 16 zeros past it
-        double ht[16];
+        float ht[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) ht[u] = hn[u];
 #pragma unroll
         for (int u = 0; u < 16; u++) hn[u] = hv[p0 + 16 + u];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            blk -= 6;
-            double prev[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) prev[r] = nxt[r];
-            if (p0 + 4 * g + 4 < L4) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) nxt[r] = blk[r - 6];
-            }
-            const double h0 = ht[4 * g], h1 = ht[4 * g + 1], h2 = ht[4 * g + 2], h3 = ht[4 * g + 3];
-            acc[0] = fma(h0, cur[0], acc[0]); acc[1] = fma(h0, cur[1], acc[1]); acc[2] = fma(h0, cur[2], acc[2]); acc[3] = fma(h0, cur[3], acc[3]);
-            acc[0] = fma(h1, prev[3], acc[0]); acc[1] = fma(h1, cur[0], acc[1]); acc[2] = fma(h1, cur[1], acc[2]); acc[3] = fma(h1, cur[2], acc[3]);
-            acc[0] = fma(h2, prev[2], acc[0]); acc[1] = fma(h2, prev[3], acc[1]); acc[2] = fma(h2, cur[0], acc[2]); acc[3] = fma(h2, cur[1], acc[3]);
-            acc[0] = fma(h3, prev[1], acc[0]); acc[1] = fma(h3, prev[2], acc[1]); acc[2] = fma(h3, prev[3], acc[2]); acc[3] = fma(h3, cur[0], acc[3]);
-#pragma unroll
-            for (int r = 0; r < 4; r++) cur[r] = prev[r];
+            blk -= 1;
+            const float4 prev = nxt;
+            if (p0 + 4 * g + 4 < L4) nxt = blk[-1];
+            const float h0 = ht[4 * g], h1 = ht[4 * g + 1], h2 = ht[4 * g + 2], h3 = ht[4 * g + 3];
+            a0 = fmaf(h0, cur.x, a0); a1 = fmaf(h0, cur.y, a1); a2 = fmaf(h0, cur.z, a2); a3 = fmaf(h0, cur.w, a3);
+            a0 = fmaf(h1, prev.w, a0); a1 = fmaf(h1, cur.x, a1); a2 = fmaf(h1, cur.y, a2); a3 = fmaf(h1, cur.z, a3);
+            a0 = fmaf(h2, prev.z, a0); a1 = fmaf(h2, prev.w, a1); a2 = fmaf(h2, cur.x, a2); a3 = fmaf(h2, cur.y, a3);
+            a0 = fmaf(h3, prev.y, a0); a1 = fmaf(h3, prev.z, a1); a2 = fmaf(h3, prev.w, a2); a3 = fmaf(h3, cur.x, a3);
+            cur = prev;
         }
+        acc[0] += (double)a0; acc[1] += (double)a1; acc[2] += (double)a2; acc[3] += (double)a3;
     }
     float2 *y = out + (long long)c * out_pitch + s + 4 * tid;
 #pragma unroll

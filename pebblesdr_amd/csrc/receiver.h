@@ -143,7 +143,7 @@ struct WfmCore {
     double *d_lp_state[2] = {nullptr, nullptr}, *d_dn_state[2] = {nullptr, nullptr};
     bool fused = false;             // single-kernel FIR-ised path (k_wfm_fir); else the multi-kernel sequential fallback
     int L4 = 0, Llp = 1;            // fused: combined audio response (padded to 16) and low-pass response lengths
-    double *d_h = nullptr;          // [L4]
+    float *d_h = nullptr;           // [L4 + 16]
     float *d_hlp = nullptr;         // [Llp]
     float2 *d_xtail[2] = {nullptr, nullptr};  // [C][L4 + Llp] input history, ping-pong
     int init(uint32_t channels, double demod_rate, long long max_n);
