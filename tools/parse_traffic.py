@@ -8,15 +8,23 @@ import collections
 import csv
 import glob
 import json
+import sqlite3
 import sys
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    """per-kernel values of one counter from a rocprofv3 --pmc run: CSV output if present, else the rocpd database"""
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    csvs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if csvs:
+        for r in csv.DictReader(open(csvs[0])):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        return acc
+    for fn in glob.glob(d + "/**/*_results.db", recursive=True):
+        db = sqlite3.connect(fn)
+        for name, val in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            acc[name].append(float(val))
     return acc
 
 
@@ -35,8 +43,8 @@ def main(fetch_dir, write_dir, out):
         f, w = first(fe, key), first(wr, key)
         cal[lanes] = {"fetch_KiB": f, "write_KiB": w, "read_scale": gib / (f * 1024.0), "write_scale": gib / (w * 1024.0)}
     res = {"calibration": cal, "kernels": {}}
-    # loads: k_spectrum and k_wfm_mono/k_cascade use 8-byte lanes, k_mix_dec1 16-byte lanes; stores: spectrum 16-byte, rest 8-byte
-    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_cascade": (8, 8), "k_wfm_mono": (8, 8)}
+    # loads: k_spectrum and k_wfm_fir/k_cascade use 8-byte lanes, k_mix_dec1 16-byte lanes; stores: spectrum 16-byte, rest 8-byte
+    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_cascade": (8, 8), "k_wfm_fir": (8, 8)}
     for name, (lr, lw) in lanes.items():
         f, w = first(fe, name), first(wr, name)
         if f is None:
