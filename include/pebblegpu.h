@@ -98,7 +98,11 @@ typedef struct {
     uint32_t fastfir_fft;        /* 0 -> 2048 (fastfir.cpp:65) */
     uint32_t fastfir_taps;       /* 0 -> 1025 (fastfir.cpp:66) */
     uint32_t max_superframes;    /* capacity of one process call, in super-frames (>=1) */
-    uint32_t reserved[5];
+    uint32_t audio_rate;         /* 0: audio stays at the demod rate (resampRate == 1, receiver.cpp:1002-1003); else
+                                    Key_AudioOutputSampleRate (receiver.cpp:203, default 11025): the audio buffer is
+                                    CFractResampler::Resample(n, demodRate / audio_rate, ...) of the demodulated frames
+                                    (receiver.cpp:994-1001, pebblelib/fractresampler.cpp:149-195) */
+    uint32_t reserved[4];
 } pebblegpu_config;
 
 int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out);
@@ -129,10 +133,19 @@ int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_h
  * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM (mono).  FMS (stereo + RDS) is a
  * later row. */
 int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
+/* AGC::setAgcMode(mode, threshold) (application/agc.cpp:53-82; Receiver::agcModeChanged/agcThresholdChanged).
+ * agc_mode: the reference's AgcMode values.  With PEBBLEGPU_AGC_OFF the threshold is a manual gain slider in dB
+ * (amplitude 10^((threshold/5)/20), integer division as written, agc.cpp:239-246; the constructor's OFF/1 is unit
+ * gain); otherwise it is the knee (0..120, negated inside).  Narrow banks only: the WFM branch has no AGC step. */
+typedef enum pebblegpu_agc_mode {
+    PEBBLEGPU_AGC_OFF = 0, PEBBLEGPU_AGC_FAST = 1, PEBBLEGPU_AGC_MED = 2, PEBBLEGPU_AGC_SLOW = 3, PEBBLEGPU_AGC_LONG = 4
+} pebblegpu_agc_mode;
+int pebblegpu_set_agc(pebblegpu_receiver *rx, uint32_t channel, int agc_mode, int threshold);
 
 /* Batched device path.  d_iq: n_streams x n_samples float2 (stream-major, [stream][time]); n_samples must be
  * k * superframe (k <= max_superframes).  Outputs (library-owned device buffers, valid until the next call):
- *   audio    [channel][k * frames_per_buffer] float2  (re = left, im = right, receiver.cpp:1029)
+ *   audio    [channel][k * frames_per_buffer] float2  (re = left, im = right, receiver.cpp:1029); with audio_rate
+ *            set, the resampled audio instead: the count pebblegpu_receiver_audio reports (same for all channels)
  *   spectrum [stream][n_samples / frames_per_buffer][bins] float, dB amplitude, -f..+f (fft.cpp:395) */
 int pebblegpu_receiver_process(pebblegpu_receiver *rx, const void *d_iq, uint64_t n_samples);
 /* returns channel 0's row; channel c starts *pitch_samples float2 further per channel */

@@ -72,6 +72,20 @@ def lib():
         L.po_receiver_dec_stages.argtypes = [C.c_void_p, C.c_int]
         L.po_receiver_process.restype = C.c_uint32
         L.po_receiver_process.argtypes = [C.c_void_p, _dp, C.c_uint32, _dp, _dp]
+        L.po_receiver_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.po_receiver_set_audio_rate.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_agc_new.restype = C.c_void_p
+        L.po_agc_new.argtypes = [C.c_double]
+        L.po_agc_free.argtypes = [C.c_void_p]
+        L.po_agc_set_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.po_agc_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.po_resampler_new.restype = C.c_void_p
+        L.po_resampler_new.argtypes = [C.c_int]
+        L.po_resampler_free.argtypes = [C.c_void_p]
+        L.po_resampler_process.restype = C.c_int
+        L.po_resampler_process.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp, _dp]
+        L.po_resampler_time.restype = C.c_double
+        L.po_resampler_time.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -373,6 +387,50 @@ class DemodWFM:
         return out
 
 
+class Agc:
+    """application/agc.cpp"""
+
+    def __init__(self, sample_rate):
+        self.h = lib().po_agc_new(float(sample_rate))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_agc_free(self.h)
+            self.h = None
+
+    def set_mode(self, mode, threshold):
+        lib().po_agc_set_mode(self.h, int(mode), int(threshold))
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty(len(x), dtype=np.complex128)
+        lib().po_agc_process(self.h, _ptr(x), _ptr(out), len(x))
+        return out
+
+
+class Resampler:
+    """CFractResampler (complex), pebblelib/fractresampler.cpp"""
+
+    def __init__(self, max_input):
+        self.h = lib().po_resampler_new(int(max_input))
+        self.cap = int(max_input)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_resampler_free(self.h)
+            self.h = None
+
+    @property
+    def float_time(self):
+        return lib().po_resampler_time(self.h)
+
+    def process(self, x, rate):
+        x = _c128(x)
+        out = np.empty(int(len(x) / rate) + 4, dtype=np.complex128)
+        n = lib().po_resampler_process(self.h, len(x), float(rate), _ptr(x), _ptr(out))
+        return out[:n].copy()
+
+
 class Receiver:
     """Receiver::processIQData DSP skeleton (application/receiver.cpp:758-1009)"""
 
@@ -401,6 +459,12 @@ class Receiver:
 
     def dec_stages(self, wfm=False):
         return lib().po_receiver_dec_stages(self.h, 1 if wfm else 0)
+
+    def set_agc(self, mode, threshold):
+        lib().po_receiver_set_agc(self.h, int(mode), int(threshold))
+
+    def set_audio_rate(self, rate):
+        lib().po_receiver_set_audio_rate(self.h, int(rate))
 
     def process(self, frame, want_spectrum=True):
         """one frame -> (audio ndarray (possibly empty), spectrum ndarray or None)"""

@@ -733,6 +733,173 @@ void po_demod_wfm_process_mono(po_demod_wfm *d, const double *in, double *out, i
 /* ------------------------------------------------------------------------------------------------
  * Receiver::processIQData skeleton -- application/receiver.cpp
  * ---------------------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------------------
+ * AGC -- application/agc.{h,cpp}
+ * ---------------------------------------------------------------------------------------------- */
+#define PO_AGC_MAX_DELAY_BUF 2048 /* agc.h MAX_DELAY_BUF */
+struct po_agc {
+    int mode;
+    double step_rate;      /* ProcessStep::sampleRate */
+    int use_hang, threshold, decay;
+    double manual_gain, sample_rate, slope_factor;
+    double decay_avg, attack_avg, attack_rise, attack_fall, decay_rise, decay_fall;
+    double fixed_gain, knee, gain_slope, peak;
+    int sig_ptr, mag_pos, delay_samples, window_samples, hang_time, hang_timer;
+    double sig[2 * PO_AGC_MAX_DELAY_BUF];
+    double mag[PO_AGC_MAX_DELAY_BUF];
+};
+
+/* agc.h: the time constants are float constexprs; they promote to double in the products below */
+static const float kAgcDelayTc = .015f, kAgcWindowTc = .018f, kAgcAttackRiseTc = .002f, kAgcAttackFallTc = .005f,
+                   kAgcDecayRatio = .3f, kAgcReleaseTc = .05f, kAgcOutScale = 0.7f, kAgcMaxAmp = 1.0f, kAgcMinConst = 1e-8f;
+
+static void po_agc_set_parameters(po_agc *a, int use_hang, int threshold, int slope_factor, int decay)
+{
+    if (a->mode == 0) { /* agc.cpp:239-246: manual gain, slider dB / 5 in integer arithmetic */
+        a->manual_gain = pow(10, (double)(threshold / 5) / 20.0);
+        return;
+    }
+    threshold = -threshold;
+    a->manual_gain = 1;
+    if (use_hang == a->use_hang && threshold == a->threshold && (double)slope_factor == a->slope_factor && decay == a->decay) return;
+    a->use_hang = use_hang; a->threshold = threshold; a->slope_factor = slope_factor; a->decay = decay;
+    if (a->sample_rate != a->step_rate) { /* :262-277 */
+        a->sample_rate = a->step_rate;
+        for (int i = 0; i < PO_AGC_MAX_DELAY_BUF; i++) { a->sig[2 * i] = a->sig[2 * i + 1] = 0.0; a->mag[i] = -16.0; }
+        a->sig_ptr = 0; a->hang_timer = 0; a->peak = -16.0; a->decay_avg = -5.0; a->attack_avg = -5.0; a->mag_pos = 0;
+    }
+    a->knee = (double)a->threshold / 20.0;
+    a->gain_slope = a->slope_factor / 100.0;
+    a->fixed_gain = kAgcOutScale * pow(10.0, a->knee * (a->gain_slope - 1.0));
+    a->attack_rise = 1.0 - exp(-1.0 / (a->sample_rate * kAgcAttackRiseTc));
+    a->attack_fall = 1.0 - exp(-1.0 / (a->sample_rate * kAgcAttackFallTc));
+    a->decay_rise = 1.0 - exp(-1.0 / (a->sample_rate * (double)a->decay * .001 * kAgcDecayRatio));
+    a->hang_time = (int)(a->sample_rate * (double)a->decay * .001);
+    if (a->use_hang) a->decay_fall = 1.0 - exp(-1.0 / (a->sample_rate * kAgcReleaseTc));
+    else a->decay_fall = 1.0 - exp(-1.0 / (a->sample_rate * (double)a->decay * .001));
+    a->delay_samples = (int)(a->sample_rate * kAgcDelayTc);
+    a->window_samples = (int)(a->sample_rate * kAgcWindowTc);
+    if (a->delay_samples >= PO_AGC_MAX_DELAY_BUF - 1) a->delay_samples = PO_AGC_MAX_DELAY_BUF - 1;
+}
+
+void po_agc_set_mode(po_agc *a, int mode, int threshold)
+{
+    int decay = 200;
+    a->mode = mode;
+    if (mode == 1) decay = 100; else if (mode == 3) decay = 500; else if (mode == 2) decay = 250; else if (mode == 4) decay = 2000;
+    po_agc_set_parameters(a, 0, threshold, 0, decay);
+}
+
+po_agc *po_agc_new(double sample_rate)
+{
+    po_agc *a = (po_agc *)calloc(1, sizeof(*a));
+    a->step_rate = sample_rate;
+    a->sample_rate = 100.0; /* "Trigger init on first call to setup" */
+    po_agc_set_mode(a, 0, 1);
+    return a;
+}
+void po_agc_free(po_agc *a) { free(a); }
+
+void po_agc_process(po_agc *a, const double *in, double *out, int n)
+{
+    if (a->mode == 0) {
+        for (int i = 0; i < 2 * n; i++) out[i] = a->manual_gain * in[i];
+        return;
+    }
+    for (int i = 0; i < n; i++) {
+        const double ir = in[2 * i], ii = in[2 * i + 1];
+        const double dr = a->sig[2 * a->sig_ptr], di = a->sig[2 * a->sig_ptr + 1];
+        a->sig[2 * a->sig_ptr] = ir; a->sig[2 * a->sig_ptr + 1] = ii;
+        if (++a->sig_ptr >= a->delay_samples) a->sig_ptr = 0;
+        double mag = fabs(ir);
+        const double mim = fabs(ii);
+        if (mim > mag) mag = mim;
+        mag = log10(mag + kAgcMinConst) - log10(kAgcMaxAmp);
+        double tmp = a->mag[a->mag_pos];
+        a->mag[a->mag_pos++] = mag;
+        if (a->mag_pos >= a->window_samples) a->mag_pos = 0;
+        if (mag > a->peak) a->peak = mag;
+        else if (tmp == a->peak) {
+            a->peak = -8.0;
+            for (int k = 0; k < a->window_samples; k++) if (a->mag[k] > a->peak) a->peak = a->mag[k];
+        }
+        if (a->peak > a->attack_avg) a->attack_avg = (1.0 - a->attack_rise) * a->attack_avg + a->attack_rise * a->peak;
+        else a->attack_avg = (1.0 - a->attack_fall) * a->attack_avg + a->attack_fall * a->peak;
+        if (a->use_hang) {
+            if (a->peak > a->decay_avg) { a->decay_avg = (1.0 - a->decay_rise) * a->decay_avg + a->decay_rise * a->peak; a->hang_timer = 0; }
+            else if (a->hang_timer < a->hang_time) a->hang_timer++;
+            else a->decay_avg = (1.0 - a->decay_fall) * a->decay_avg + a->decay_fall * a->peak;
+        } else {
+            if (a->peak > a->decay_avg) a->decay_avg = (1.0 - a->decay_rise) * a->decay_avg + a->decay_rise * a->peak;
+            else a->decay_avg = (1.0 - a->decay_fall) * a->decay_avg + a->decay_fall * a->peak;
+        }
+        mag = a->attack_avg > a->decay_avg ? a->attack_avg : a->decay_avg;
+        double gain;
+        if (mag <= a->knee) gain = a->fixed_gain;
+        else gain = kAgcOutScale * pow(10.0, mag * (a->gain_slope - 1.0));
+        out[2 * i] = dr * gain;
+        out[2 * i + 1] = di * gain;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CFractResampler -- pebblelib/fractresampler.cpp
+ * ---------------------------------------------------------------------------------------------- */
+#define PO_SINC_PERIOD_PTS 10000
+#define PO_SINC_PERIODS 28
+#define PO_SINC_LENGTH (PO_SINC_PERIODS * PO_SINC_PERIOD_PTS + 1)
+struct po_resampler {
+    double *sinc, *inbuf;
+    int cap;
+    double float_time;
+};
+
+void po_resampler_sinc_table(double *t) /* fractresampler.cpp:104-118 */
+{
+    for (int i = 0; i < PO_SINC_LENGTH; i++) {
+        const double window = (0.35875 - 0.48829 * cos((PO_TWOPI * i) / (PO_SINC_LENGTH - 1)) + 0.14128 * cos((2.0 * PO_TWOPI * i) / (PO_SINC_LENGTH - 1)) -
+                               0.01168 * cos((3.0 * PO_TWOPI * i) / (PO_SINC_LENGTH - 1)));
+        const double fi = PO_PI * (double)(i - PO_SINC_LENGTH / 2) / (double)PO_SINC_PERIOD_PTS;
+        t[i] = i != PO_SINC_LENGTH / 2 ? window * sin(fi) / fi : 1.0;
+    }
+}
+
+po_resampler *po_resampler_new(int max_input)
+{
+    po_resampler *r = (po_resampler *)calloc(1, sizeof(*r));
+    r->cap = max_input + PO_SINC_PERIODS;
+    r->sinc = (double *)malloc(sizeof(double) * PO_SINC_LENGTH);
+    r->inbuf = (double *)calloc((size_t)r->cap * 2, sizeof(double));
+    po_resampler_sinc_table(r->sinc);
+    r->float_time = 0.0;
+    return r;
+}
+void po_resampler_free(po_resampler *r) { if (r) { free(r->sinc); free(r->inbuf); free(r); } }
+double po_resampler_time(const po_resampler *r) { return r->float_time; }
+
+int po_resampler_process(po_resampler *r, int n, double rate, const double *in, double *out)
+{
+    int integer_time = (int)r->float_time, outsamples = 0;
+    const double dt = rate;
+    memcpy(r->inbuf + 2 * PO_SINC_PERIODS, in, sizeof(double) * 2 * (size_t)n);
+    while (integer_time < n) {
+        double ar = 0.0, ai = 0.0;
+        for (int i = 1; i <= PO_SINC_PERIODS; i++) {
+            const int j = integer_time + i;
+            const int sindx = (int)(((double)j - r->float_time) * (double)PO_SINC_PERIOD_PTS);
+            ar = ar + (r->inbuf[2 * j] * r->sinc[sindx]);
+            ai = ai + (r->inbuf[2 * j + 1] * r->sinc[sindx]);
+        }
+        out[2 * outsamples] = ar; out[2 * outsamples + 1] = ai;
+        outsamples++;
+        r->float_time += dt;
+        integer_time = (int)r->float_time;
+    }
+    r->float_time -= (double)n;
+    memmove(r->inbuf, r->inbuf + 2 * (size_t)n, sizeof(double) * 2 * PO_SINC_PERIODS);
+    return outsamples;
+}
+
 struct po_receiver {
     uint32_t fs, n;
     int mode;
@@ -747,6 +914,9 @@ struct po_receiver {
     po_demod_wfm wfm;
     double *mixed, *working, *samplebuf, *bpout, *demodout;
     uint32_t samplebuf_len;
+    po_agc *agc;             /* receiver.cpp:264 AGC(m_demodSampleRate, m_demodFrames) */
+    po_resampler *resamp;    /* receiver.cpp:184 */
+    uint32_t audio_rate;     /* 0: resampRate == 1 branch (copyCPX) */
 };
 
 po_receiver *po_receiver_new(uint32_t fs, uint32_t n, uint32_t spectrum_bins, uint32_t fastfir_fft, uint32_t fastfir_taps)
@@ -768,7 +938,10 @@ po_receiver *po_receiver_new(uint32_t fs, uint32_t n, uint32_t spectrum_bins, ui
     r->working = (double *)calloc((size_t)n * 2, sizeof(double));
     r->samplebuf = (double *)calloc((size_t)n * 2, sizeof(double));
     r->bpout = (double *)calloc((size_t)n * 2 + 2 * (size_t)(fastfir_fft ? fastfir_fft : 2048), sizeof(double));
-    r->demodout = (double *)calloc((size_t)n * 2, sizeof(double));
+    r->demodout = (double *)calloc((size_t)n * 2 + 2 * (size_t)(fastfir_fft ? fastfir_fft : 2048), sizeof(double));
+    r->agc = po_agc_new((double)r->demod_rate);
+    r->resamp = po_resampler_new((int)n + (int)(fastfir_fft ? fastfir_fft : 2048));
+    r->audio_rate = 0;
     return r;
 }
 
@@ -778,6 +951,7 @@ void po_receiver_free(po_receiver *r)
     po_decimator_free(r->dec); po_decimator_free(r->dec_wfm);
     po_spectrum_free(r->spec); po_fastfir_free(r->bp);
     free(r->mixed); free(r->working); free(r->samplebuf); free(r->bpout); free(r->demodout);
+    po_agc_free(r->agc); po_resampler_free(r->resamp);
     free(r);
 }
 
@@ -815,8 +989,10 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     r->samplebuf_len = 0;
     if (wfm) {
         /* :896 Demod::processBlock -> fmMono (stereo is out of scope: SURVEY 8(f) rank 4) */
-        po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns);
-        return ns;
+        if (!r->audio_rate) { po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns); return ns; }
+        po_demod_wfm_process_mono(&r->wfm, r->samplebuf, r->demodout, (int)ns);
+        /* :901, :1000-1001 resampRate = m_demodWfmSampleRate / m_audioOutRate */
+        return (uint32_t)po_resampler_process(r->resamp, (int)ns, ((double)r->wfm_rate * 1.0) / ((double)r->audio_rate * 1.0), r->demodout, audio);
     }
     /* :935-938 gain restore 10^(2*stages/20) */
     double g = pow(10, (double)(po_decimator_dec_by2_stages(r->dec) * 2) / 20.0);
@@ -828,10 +1004,18 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     int nb = po_fastfir_process(r->bp, (int)ns, r->samplebuf, r->bpout);
     if (nb <= 0) return 0;
     if (r->mode == PO_NONE) { memset(audio, 0, (size_t)nb * 2 * sizeof(double)); return (uint32_t)nb; } /* :968-971 */
-    /* :987 demod (AGC/ANF identity, see header) */
-    if (r->mode == PO_AM) po_demod_am_process(&r->am, r->bpout, audio, nb);
-    else if (r->mode == PO_SAM) po_demod_sam_process(&r->sam, r->bpout, audio, nb);
-    else if (r->mode == PO_FMN) po_demod_nfm_process(&r->nfm, r->bpout, audio, nb);
-    else memcpy(audio, r->bpout, (size_t)nb * 2 * sizeof(double)); /* SSB/CW/DIG/DSB pass-through, demod.cpp:127-138 */
-    return (uint32_t)nb;
+    /* :983 AGC (ANF identity, see header), written back over the band-pass output buffer */
+    po_agc_process(r->agc, r->bpout, r->bpout, nb);
+    /* :987 demod */
+    double *dst = r->audio_rate ? r->demodout : audio;
+    if (r->mode == PO_AM) po_demod_am_process(&r->am, r->bpout, dst, nb);
+    else if (r->mode == PO_SAM) po_demod_sam_process(&r->sam, r->bpout, dst, nb);
+    else if (r->mode == PO_FMN) po_demod_nfm_process(&r->nfm, r->bpout, dst, nb);
+    else memcpy(dst, r->bpout, (size_t)nb * 2 * sizeof(double)); /* SSB/CW/DIG/DSB pass-through, demod.cpp:127-138 */
+    if (!r->audio_rate) return (uint32_t)nb;
+    /* :994, :1000-1001 */
+    return (uint32_t)po_resampler_process(r->resamp, nb, ((double)r->demod_rate * 1.0) / ((double)r->audio_rate * 1.0), r->demodout, audio);
 }
+
+void po_receiver_set_agc(po_receiver *r, int mode, int threshold) { po_agc_set_mode(r->agc, mode, threshold); }
+void po_receiver_set_audio_rate(po_receiver *r, uint32_t audio_rate) { r->audio_rate = audio_rate; }

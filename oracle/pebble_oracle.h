@@ -137,6 +137,27 @@ void po_demod_wfm_process_mono(po_demod_wfm *d, const double *in, double *out, i
 /* ---- Receiver::processIQData, DSP skeleton only: application/receiver.cpp:116-281, 758-1009 ----
  * Steps that are default-off / identity / GUI are omitted exactly as SURVEY.md 8(a-1) scopes them:
  * DCRemoval, IQBalance, NoiseBlanker, NoiseFilter, AGC, squelch (forced open), resampler, audio out. */
+/* ------------------------------------------------------------------------------------------------
+ * AGC -- application/agc.{h,cpp}.  modes: 0 AGC_OFF, 1 ACG_FAST, 2 AGC_MED, 3 AGC_SLOW, 4 AGC_LONG
+ * (agc.h enum AgcMode).  Parity unpinned: the reference holds no recorded values for this class.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct po_agc po_agc;
+po_agc *po_agc_new(double sample_rate);                       /* AGC::AGC, agc.cpp:15-32 */
+void po_agc_free(po_agc *a);
+void po_agc_set_mode(po_agc *a, int mode, int threshold);     /* setAgcMode + setParameters, agc.cpp:53-82,237-300 */
+void po_agc_process(po_agc *a, const double *in, double *out, int n); /* processBlock, agc.cpp:84-235 */
+
+/* ------------------------------------------------------------------------------------------------
+ * CFractResampler (complex version) -- pebblelib/fractresampler.cpp:87-195.  Parity unpinned (no
+ * recorded values in the reference).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct po_resampler po_resampler;
+po_resampler *po_resampler_new(int max_input);                /* Init, fractresampler.cpp:87-140 */
+void po_resampler_free(po_resampler *r);
+/* Resample(InLength, Rate, pIn, pOut): returns the number of output samples */
+int po_resampler_process(po_resampler *r, int n, double rate, const double *in, double *out);
+double po_resampler_time(const po_resampler *r);              /* m_FloatTime, for tests */
+
 typedef struct po_receiver po_receiver;
 po_receiver *po_receiver_new(uint32_t fs, uint32_t frames_per_buffer, uint32_t spectrum_bins,
                              uint32_t fastfir_fft, uint32_t fastfir_taps);
@@ -151,6 +172,10 @@ uint32_t po_receiver_dec_stages(const po_receiver *r, int wfm);
  * audio must hold max(frames_per_buffer, fastfir_fft) complex samples (the 8192/4097 FastFIR variant
  * emits 0 or 4096 samples per call). */
 uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, double *audio, double *spectrum_db);
+/* AGC::setAgcMode on the narrow branch (receiver.cpp:983) and the audio resampler (receiver.cpp:994-1003):
+ * audio_rate 0 leaves the audio at the demod rate (the resampRate == 1 branch) */
+void po_receiver_set_agc(po_receiver *r, int mode, int threshold);
+void po_receiver_set_audio_rate(po_receiver *r, uint32_t audio_rate);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ SYMBOLS = [
     "pebblegpu_malloc", "pebblegpu_free", "pebblegpu_memcpy_h2d", "pebblegpu_memcpy_d2h", "pebblegpu_memset",
     "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps", "pebblegpu_normalize_iq",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
-    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode",
+    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
     "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
@@ -42,7 +42,8 @@ class Config(C.Structure):
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("sample_rate", C.c_double),
         ("frames_per_buffer", C.c_uint32), ("n_channels", C.c_uint32), ("shared_input", C.c_uint32),
         ("wfm", C.c_uint32), ("spectrum_bins", C.c_uint32), ("fastfir_fft", C.c_uint32),
-        ("fastfir_taps", C.c_uint32), ("max_superframes", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("fastfir_taps", C.c_uint32), ("max_superframes", C.c_uint32), ("audio_rate", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 
@@ -88,6 +89,7 @@ def _declare(L):
     L.pebblegpu_set_mixer_freq.argtypes = [vp, u32, dbl]
     L.pebblegpu_set_bandpass.argtypes = [vp, u32, dbl, dbl]
     L.pebblegpu_set_demod_mode.argtypes = [vp, u32, i32]
+    L.pebblegpu_set_agc.argtypes = [vp, u32, i32, i32]
     L.pebblegpu_receiver_process.argtypes = [vp, vp, u64]
     L.pebblegpu_receiver_audio.restype = vp
     L.pebblegpu_receiver_audio.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -229,7 +231,7 @@ class ReceiverBank:
     """C tuned channels over one shared stream or C independent streams (pebblegpu_receiver_*)."""
 
     def __init__(self, sample_rate, n_channels=1, shared_input=True, wfm=False, spectrum_bins=0,
-                 frames_per_buffer=2048, fastfir_fft=0, fastfir_taps=0, max_superframes=1, device=0, lib=None):
+                 frames_per_buffer=2048, fastfir_fft=0, fastfir_taps=0, max_superframes=1, device=0, lib=None, audio_rate=0):
         self.L = lib or load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -243,6 +245,7 @@ class ReceiverBank:
         cfg.fastfir_fft = fastfir_fft
         cfg.fastfir_taps = fastfir_taps
         cfg.max_superframes = max_superframes
+        cfg.audio_rate = audio_rate
         self.h = C.c_void_p()
         check(self.L, self.L.pebblegpu_receiver_create(C.byref(cfg), C.byref(self.h)))
         self.device = device
@@ -278,6 +281,9 @@ class ReceiverBank:
 
     def set_mode(self, ch, mode):
         check(self.L, self.L.pebblegpu_set_demod_mode(self.h, ch, int(mode)))
+
+    def set_agc(self, ch, agc_mode, threshold):
+        check(self.L, self.L.pebblegpu_set_agc(self.h, ch, int(agc_mode), int(threshold)))
 
     def process_device(self, dptr, n_samples):
         check(self.L, self.L.pebblegpu_receiver_process(self.h, C.c_void_p(dptr), int(n_samples)))

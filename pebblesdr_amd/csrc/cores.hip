@@ -696,6 +696,191 @@ void WfmCore::tail_jobs(std::vector<TailJob> &jobs) const
 }
 
 // ------------------------------------------------------------------------------------------------
+// AgcCore
+// ------------------------------------------------------------------------------------------------
+int AgcCore::init(uint32_t channels, double demod_rate)
+{
+    C = channels;
+    rate = demod_rate;
+    host.assign(C, Host());
+    PG_HIP(hipMalloc((void **)&d_state, sizeof(AgcState) * C));
+    PG_HIP(hipMemset(d_state, 0, sizeof(AgcState) * C));
+    PG_HIP(hipMalloc((void **)&d_list, sizeof(int) * C));
+    std::vector<AgcState> init(1);
+    memset(&init[0], 0, sizeof(AgcState));
+    init[0].manual_gain = 1.0;  // AGC::AGC -> setAgcMode(AGC_OFF, 1): dBToAmplitude(1 / 5) = 1 (agc.cpp:29,241-245)
+    for (uint32_t c = 0; c < C; c++) PG_HIP(hipMemcpy(d_state + c, &init[0], offsetof(AgcState, sig), hipMemcpyHostToDevice));
+    return 0;
+}
+void AgcCore::release()
+{
+    if (d_state) (void)hipFree(d_state);
+    if (d_list) (void)hipFree(d_list);
+    d_state = nullptr;
+    d_list = nullptr;
+}
+int AgcCore::set_mode(uint32_t ch, int mode, int threshold)
+{
+    if (ch >= C || mode < 0 || mode > 4) return fail(PEBBLEGPU_E_INVALID, "bad AGC channel or mode");
+    Host &h = host[ch];
+    h.mode = mode;
+    h.threshold = threshold;
+    h.dirty = true;
+    list_dirty = true;
+    return 0;
+}
+int AgcCore::apply(hipStream_t s)
+{
+    if (!list_dirty) return 0;
+    for (uint32_t c = 0; c < C; c++) {
+        Host &h = host[c];
+        if (!h.dirty) continue;
+        h.dirty = false;
+        // setAgcMode picks the decay for the mode, then setParameters (agc.cpp:53-82, 237-300)
+        int decay = 200;
+        if (h.mode == 1) decay = 100; else if (h.mode == 3) decay = 500; else if (h.mode == 2) decay = 250; else if (h.mode == 4) decay = 2000;
+        AgcState st;
+        PG_HIP(hipStreamSynchronize(s));
+        PG_HIP(hipMemcpy(&st, d_state + c, offsetof(AgcState, sig), hipMemcpyDeviceToHost));  // running averages survive a parameter change
+        st.mode = h.mode;
+        if (h.mode == 0) {
+            st.manual_gain = std::pow(10, (double)(h.threshold / 5) / 20.0);  // integer division as written
+            h.manual = st.manual_gain;
+            PG_HIP(hipMemcpy(d_state + c, &st, offsetof(AgcState, sig), hipMemcpyHostToDevice));
+            continue;
+        }
+        const int thr = -h.threshold;
+        st.manual_gain = 1;
+        h.manual = 1;
+        if (!(h.use_hang == 0 && thr == h.thr && h.slope == 0.0 && decay == h.decay && h.sample_rate == rate)) {
+            h.use_hang = 0; h.thr = thr; h.slope = 0; h.decay = decay;
+            if (h.sample_rate != rate) {  // first set-up: clear the delay line and the averagers (agc.cpp:262-277)
+                h.sample_rate = rate;
+                std::vector<AgcState> full(1);
+                memset(&full[0], 0, sizeof(AgcState));
+                for (int i = 0; i < kAgcMaxDelayBuf; i++) full[0].mag[i] = -16.0;
+                PG_HIP(hipMemcpy(d_state + c, &full[0], sizeof(AgcState), hipMemcpyHostToDevice));
+                st.sig_ptr = 0; st.hang_timer = 0; st.peak = -16.0; st.decay_avg = -5.0; st.attack_avg = -5.0; st.mag_pos = 0;
+            }
+            const float kDelayTc = .015f, kWindowTc = .018f, kAttackRiseTc = .002f, kAttackFallTc = .005f, kDecayRatio = .3f, kOutScale = 0.7f;
+            st.use_hang = 0;
+            st.knee = (double)thr / 20.0;
+            st.gain_slope = h.slope / 100.0;
+            st.fixed_gain = kOutScale * std::pow(10.0, st.knee * (st.gain_slope - 1.0));
+            st.attack_rise = 1.0 - std::exp(-1.0 / (rate * kAttackRiseTc));
+            st.attack_fall = 1.0 - std::exp(-1.0 / (rate * kAttackFallTc));
+            st.decay_rise = 1.0 - std::exp(-1.0 / (rate * (double)decay * .001 * kDecayRatio));
+            st.hang_time = (int)(rate * (double)decay * .001);
+            st.decay_fall = 1.0 - std::exp(-1.0 / (rate * (double)decay * .001));
+            st.delay_samples = (int)(rate * kDelayTc);
+            st.window_samples = (int)(rate * kWindowTc);
+            if (st.delay_samples >= kAgcMaxDelayBuf - 1) st.delay_samples = kAgcMaxDelayBuf - 1;
+            if (st.window_samples > kAgcMaxDelayBuf) return fail(PEBBLEGPU_E_UNSUPPORTED, "AGC window of %d samples exceeds the reference's own buffer", st.window_samples);
+        }
+        PG_HIP(hipMemcpy(d_state + c, &st, offsetof(AgcState, sig), hipMemcpyHostToDevice));
+    }
+    list.clear();
+    for (uint32_t c = 0; c < C; c++)
+        if (host[c].mode != 0 || host[c].manual != 1.0) list.push_back((int)c);
+    if (!list.empty()) PG_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, s));
+    PG_HIP(hipStreamSynchronize(s));
+    list_dirty = false;
+    return 0;
+}
+int AgcCore::run(hipStream_t s, float2 *buf, long long pitch, long long n)
+{
+    if (list.empty()) return 0;  // AGC_OFF with unit manual gain: out = 1.0 * in
+    launch(k_agc, dim3(cdiv((long long)list.size(), 64)), dim3(64), s, buf, pitch, n, d_state, (const int *)d_list, (int)list.size());
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ResampCore
+// ------------------------------------------------------------------------------------------------
+int ResampCore::init(uint32_t channels, uint32_t frame, double rate, uint32_t frames_per_call)
+{
+    C = channels;
+    nf = frame;
+    dt = rate;
+    max_frames = frames_per_call;
+    if (!(dt > 0) || dt > 1e6) return fail(PEBBLEGPU_E_INVALID, "bad resampling ratio");
+    std::vector<float> t((size_t)kSincLength);
+    for (int i = 0; i < kSincLength; i++) {  // fractresampler.cpp:104-118
+        const double window = (0.35875 - 0.48829 * std::cos((design::kTwoPi * i) / (kSincLength - 1)) +
+                               0.14128 * std::cos((2.0 * design::kTwoPi * i) / (kSincLength - 1)) -
+                               0.01168 * std::cos((3.0 * design::kTwoPi * i) / (kSincLength - 1)));
+        const double fi = (design::kTwoPi / 2.0) * (double)(i - kSincLength / 2) / (double)kSincPeriodPts;
+        t[i] = (float)(i != kSincLength / 2 ? window * std::sin(fi) / fi : 1.0);
+    }
+    PG_HIP(hipMalloc((void **)&d_sinc, sizeof(float) * kSincLength));
+    PG_HIP(hipMemcpy(d_sinc, t.data(), sizeof(float) * kSincLength, hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; i++) {
+        PG_HIP(hipMalloc((void **)&d_hist[i], sizeof(float2) * kSincPeriods * C));
+        PG_HIP(hipMemset(d_hist[i], 0, sizeof(float2) * kSincPeriods * C));  // Init zeroes m_pInputBuf
+        PG_HIP(hipHostMalloc((void **)&h_frames[i], sizeof(ResampFrame) * max_frames));
+        PG_HIP(hipEventCreateWithFlags(&h_done[i], hipEventDisableTiming));
+    }
+    PG_HIP(hipMalloc((void **)&d_frames, sizeof(ResampFrame) * max_frames));
+    return 0;
+}
+void ResampCore::release()
+{
+    if (d_sinc) (void)hipFree(d_sinc);
+    if (d_frames) (void)hipFree(d_frames);
+    for (int i = 0; i < 2; i++) {
+        if (d_hist[i]) (void)hipFree(d_hist[i]);
+        if (h_frames[i]) (void)hipHostFree(h_frames[i]);
+        if (h_done[i]) (void)hipEventDestroy(h_done[i]);
+        d_hist[i] = nullptr; h_frames[i] = nullptr; h_done[i] = nullptr;
+    }
+    d_sinc = nullptr;
+    d_frames = nullptr;
+}
+int ResampCore::run(hipStream_t s, const float2 *in, long long in_pitch, long long n, float2 *out, long long out_pitch, long long *n_out)
+{
+    if (n % nf != 0 || n / nf > (long long)max_frames) return fail(PEBBLEGPU_E_SIZE, "resampler input %lld is not 1..%u frames of %u", n, max_frames, nf);
+    if (n < kSincPeriods) return fail(PEBBLEGPU_E_SIZE, "resampler needs at least %d samples per call", kSincPeriods);
+    const int F = (int)(n / nf);
+    PG_HIP(hipEventSynchronize(h_done[pin]));  // the copy that last used this staging buffer has run
+    ResampFrame *hf = h_frames[pin];
+    // replay of the reference's time arithmetic, frame by frame (fractresampler.cpp:155-187)
+    double t = float_time;
+    int total = 0, max_per_frame = 0;
+    for (int f = 0; f < F; f++) {
+        hf[f].t_start = t;
+        hf[f].out_offset = total;
+        int it = (int)t, cnt = 0;
+        while (it < (int)nf) {
+            cnt++;
+            t += dt;
+            it = (int)t;
+        }
+        t -= (double)nf;
+        hf[f].nout = cnt;
+        total += cnt;
+        if (cnt > max_per_frame) max_per_frame = cnt;
+    }
+    float_time = t;
+    *n_out = total;
+    if (total > out_pitch) return fail(PEBBLEGPU_E_SIZE, "resampler output %d exceeds its buffer", total);
+    PG_HIP(hipMemcpyAsync(d_frames, hf, sizeof(ResampFrame) * F, hipMemcpyHostToDevice, s));
+    PG_HIP(hipEventRecord(h_done[pin], s));
+    pin ^= 1;
+    if (total > 0) {
+        const int sub = (int)cdiv(max_per_frame, 256);
+        launch(k_resample, dim3((unsigned)(F * sub), C), dim3(256), s, in, in_pitch, (const float2 *)d_hist[parity], out, out_pitch, (int)nf, sub, dt,
+               (const ResampFrame *)d_frames, (const float *)d_sinc);
+        PG_HIP(hipGetLastError());
+    }
+    // m_pInputBuf[0..27] <- the last 28 inputs (fractresampler.cpp:189-193)
+    PG_HIP(hipMemcpy2DAsync(d_hist[parity ^ 1], sizeof(float2) * kSincPeriods, in + (n - kSincPeriods), sizeof(float2) * in_pitch,
+                            sizeof(float2) * kSincPeriods, C, hipMemcpyDeviceToDevice, s));
+    parity ^= 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SpectrumCore
 // ------------------------------------------------------------------------------------------------
 int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)

@@ -354,4 +354,120 @@ static __global__ __launch_bounds__(256) void k_copy(const float2 *__restrict__ 
     if (i < n) out[(long long)c * out_pitch + i] = in[(long long)c * in_pitch + i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// AGC::processBlock (application/agc.cpp:84-235): delay line, sliding-window peak of log magnitudes, attack/decay
+// averagers, gain from the knee curve.  Non-linear feedback with data-dependent control flow: serial in time, one lane
+// per listed channel, fp64 state as the reference declares it; in place on the band-passed samples.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAgcMaxDelayBuf = 2048;  // agc.h MAX_DELAY_BUF
+struct AgcState {        // per channel, device resident
+    int mode, use_hang, delay_samples, window_samples, hang_time, hang_timer, sig_ptr, mag_pos;
+    double manual_gain, decay_avg, attack_avg, attack_rise, attack_fall, decay_rise, decay_fall, fixed_gain, knee, gain_slope, peak;
+    float2 sig[kAgcMaxDelayBuf];
+    double mag[kAgcMaxDelayBuf];
+};
+
+static __global__ __launch_bounds__(64) void k_agc(float2 *__restrict__ buf, long long pitch, long long n, AgcState *__restrict__ st,
+                                                   const int *__restrict__ chan_list, int nlist)
+{
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nlist) return;
+    const int c = chan_list[li];
+    float2 *x = buf + (long long)c * pitch;
+    AgcState *a = st + c;
+    if (a->mode == 0) {  // manual gain, agc.cpp:86-95
+        const double g = a->manual_gain;
+        for (long long i = 0; i < n; i++) x[i] = make_float2((float)(g * (double)x[i].x), (float)(g * (double)x[i].y));
+        return;
+    }
+    const float out_scale = 0.7f, min_const = 1e-8f, max_amp = 1.0f;  // agc.h: float constants
+    int sig_ptr = a->sig_ptr, mag_pos = a->mag_pos, hang_timer = a->hang_timer;
+    const int delay_samples = a->delay_samples, window_samples = a->window_samples, hang_time = a->hang_time, use_hang = a->use_hang;
+    double peak = a->peak, attack_avg = a->attack_avg, decay_avg = a->decay_avg;
+    const double ar = a->attack_rise, af = a->attack_fall, dr = a->decay_rise, df = a->decay_fall;
+    const double knee = a->knee, gain_slope = a->gain_slope, fixed_gain = a->fixed_gain;
+    for (long long i = 0; i < n; i++) {
+        const float2 in = x[i];
+        const float2 delayed = a->sig[sig_ptr];
+        a->sig[sig_ptr++] = in;
+        if (sig_ptr >= delay_samples) sig_ptr = 0;
+        double mag = fabs((double)in.x);
+        const double mim = fabs((double)in.y);
+        if (mim > mag) mag = mim;
+        mag = log10(mag + (double)min_const) - log10((double)max_amp);
+        double tmp = a->mag[mag_pos];
+        a->mag[mag_pos++] = mag;
+        if (mag_pos >= window_samples) mag_pos = 0;
+        if (mag > peak) {
+            peak = mag;
+        } else if (tmp == peak) {
+            peak = -8.0;
+            for (int k = 0; k < window_samples; k++) {
+                tmp = a->mag[k];
+                if (tmp > peak) peak = tmp;
+            }
+        }
+        if (peak > attack_avg) attack_avg = (1.0 - ar) * attack_avg + ar * peak;
+        else attack_avg = (1.0 - af) * attack_avg + af * peak;
+        if (use_hang) {
+            if (peak > decay_avg) { decay_avg = (1.0 - dr) * decay_avg + dr * peak; hang_timer = 0; }
+            else if (hang_timer < hang_time) hang_timer++;
+            else decay_avg = (1.0 - df) * decay_avg + df * peak;
+        } else {
+            if (peak > decay_avg) decay_avg = (1.0 - dr) * decay_avg + dr * peak;
+            else decay_avg = (1.0 - df) * decay_avg + df * peak;
+        }
+        mag = attack_avg > decay_avg ? attack_avg : decay_avg;
+        const double gain = mag <= knee ? fixed_gain : (double)out_scale * pow(10.0, mag * (gain_slope - 1.0));
+        x[i] = make_float2((float)((double)delayed.x * gain), (float)((double)delayed.y * gain));
+    }
+    a->sig_ptr = sig_ptr; a->mag_pos = mag_pos; a->hang_timer = hang_timer;
+    a->peak = peak; a->attack_avg = attack_avg; a->decay_avg = decay_avg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFractResampler::Resample, complex version (pebblelib/fractresampler.cpp:149-195): every output convolves 28 input
+// samples with a windowed sinc read from a 280 001-point table at floor((j - t) * 10000).  The output times t are the
+// reference's running fp64 sum (m_FloatTime += dt per output, -= InLength per frame); the host replays that sum per
+// call -- it also yields the output count without a device sync -- and hands each frame's start time to the kernel,
+// which re-adds dt in the same order, so every table index is the reference's own.
+// grid (frames * sub_blocks, channels), block 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSincPeriodPts = 10000, kSincPeriods = 28, kSincLength = kSincPeriods * kSincPeriodPts + 1;
+struct ResampFrame { double t_start; int out_offset, nout; };
+
+static __global__ __launch_bounds__(256) void k_resample(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ hist,
+                                                         float2 *__restrict__ out, long long out_pitch, int nf, int sub_blocks, double dt,
+                                                         const ResampFrame *__restrict__ frames, const float *__restrict__ sinc)
+{
+    __shared__ double tk[256];
+    const int f = blockIdx.x / sub_blocks, sb = blockIdx.x % sub_blocks, c = blockIdx.y, tid = threadIdx.x;
+    const ResampFrame fr = frames[f];
+    if (sb * 256 >= fr.nout) return;
+    if (tid == 0) {
+        double t = fr.t_start;
+        for (int k = 0; k < sb * 256; k++) t += dt;
+        for (int k = 0; k < 256; k++) { tk[k] = t; t += dt; }
+    }
+    __syncthreads();
+    const int k = sb * 256 + tid;
+    if (k >= fr.nout) return;
+    const double t = tk[tid];
+    const int it = (int)t;
+    // m_pInputBuf[j], j = it + i: [28 samples of history | this frame]; frame f of the call starts at in[f * nf]
+    const float2 *x = in + (long long)c * in_pitch + (long long)f * nf - kSincPeriods;
+    const float2 *h = hist + (long long)c * kSincPeriods;
+    double ar = 0.0, ai = 0.0;
+#pragma unroll 4
+    for (int i = 1; i <= kSincPeriods; i++) {
+        const int j = it + i;
+        const int sindx = (int)(((double)j - t) * (double)kSincPeriodPts);
+        const float2 v = (f == 0 && j < kSincPeriods) ? h[j] : x[j];
+        const double w = (double)sinc[sindx];
+        ar = ar + (double)v.x * w;
+        ai = ai + (double)v.y * w;
+    }
+    out[(long long)c * out_pitch + fr.out_offset + k] = make_float2((float)ar, (float)ai);
+}
+
 }  // namespace pg

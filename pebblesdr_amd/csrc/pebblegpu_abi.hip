@@ -139,6 +139,11 @@ int pebblegpu_set_bandpass(pebblegpu_receiver *h, uint32_t channel, double lo_hz
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
     return h->rx.set_bandpass(channel, lo_hz, hi_hz);
 }
+int pebblegpu_set_agc(pebblegpu_receiver *h, uint32_t channel, int agc_mode, int threshold)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_agc(channel, agc_mode, threshold);
+}
 int pebblegpu_set_demod_mode(pebblegpu_receiver *h, uint32_t channel, int mode)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
@@ -154,8 +159,8 @@ const void *pebblegpu_receiver_audio(const pebblegpu_receiver *h, uint64_t *samp
 {
     if (!h) return nullptr;
     if (samples_per_channel) *samples_per_channel = h->rx.last_audio_n;
-    if (pitch_samples) *pitch_samples = (uint64_t)h->rx.audio.pitch;
-    return h->rx.audio.data(0);
+    if (pitch_samples) *pitch_samples = (uint64_t)h->rx.audio_pitch();
+    return h->rx.audio_ptr();
 }
 const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *h, uint64_t *frames_per_stream)
 {

@@ -153,6 +153,40 @@ struct WfmCore {
     long long last_n = 0;
 };
 
+// ---- AGC (application/agc.cpp), on the band-passed samples of the narrow branch ----
+struct AgcCore {
+    uint32_t C = 0;
+    double rate = 0;
+    struct AgcState *d_state = nullptr;
+    int *d_list = nullptr;
+    std::vector<int> list;          // channels the kernel visits: every mode but OFF-with-unit-gain
+    struct Host { int mode = 0, threshold = 1, use_hang = 0, thr = 0, decay = 0; double slope = 0, sample_rate = 100.0, manual = 1.0; bool dirty = false; };
+    std::vector<Host> host;
+    int init(uint32_t channels, double demod_rate);
+    void release();
+    int set_mode(uint32_t ch, int mode, int threshold);      // AGC::setAgcMode, agc.cpp:53-82
+    int apply(hipStream_t s);                                // upload changed parameters and the channel list
+    int run(hipStream_t s, float2 *buf, long long pitch, long long n);
+    bool list_dirty = false;
+};
+
+// ---- CFractResampler (complex), pebblelib/fractresampler.cpp ----
+struct ResampCore {
+    uint32_t C = 0, nf = 0;
+    double dt = 1.0, float_time = 0.0;     // Rate = input rate / output rate; m_FloatTime
+    float *d_sinc = nullptr;
+    float2 *d_hist[2] = {nullptr, nullptr};  // [C][28] last inputs of the previous call, ping-pong
+    struct ResampFrame *d_frames = nullptr, *h_frames[2] = {nullptr, nullptr};
+    hipEvent_t h_done[2] = {nullptr, nullptr};
+    int parity = 0, pin = 0;
+    uint32_t max_frames = 0;
+    int init(uint32_t channels, uint32_t frame, double rate, uint32_t frames_per_call);
+    void release();
+    long long max_out(long long n) const { return (long long)((double)n / dt) + (long long)(n / (nf ? nf : 1)) + 8; }
+    // n: multiple of the frame; returns the output count of this call in *n_out (no device sync)
+    int run(hipStream_t s, const float2 *in, long long in_pitch, long long n, float2 *out, long long out_pitch, long long *n_out);
+};
+
 // ---- FFT::fftSpectrum ----
 struct SpectrumCore {
     uint32_t S = 0, nf = 2048, bins = 0;
@@ -186,6 +220,7 @@ public:
     int set_mixer(uint32_t ch, double f);
     int set_bandpass(uint32_t ch, double lo, double hi);
     int set_mode(uint32_t ch, int mode);
+    int set_agc(uint32_t ch, int mode, int threshold);
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();
@@ -201,6 +236,11 @@ public:
     Timers tm;
     HistBuf audio;   // [C][k*nf]
     float *d_spec = nullptr;
+    uint32_t audio_rate = 0;          // 0: audio stays at the demod rate (the resampRate == 1 branch, receiver.cpp:1000-1003)
+    float2 *d_audio_rs = nullptr;     // [C][rs_pitch] resampled audio
+    long long rs_pitch = 0;
+    const float2 *audio_ptr() const { return audio_rate ? d_audio_rs : audio.data(0); }
+    long long audio_pitch() const { return audio_rate ? rs_pitch : audio.pitch; }
 
 private:
     struct ChanCtl {
@@ -220,6 +260,8 @@ private:
     AmCore am_;
     PllCore nfm_, sam_;
     WfmCore wfmc_;
+    AgcCore agc_;
+    ResampCore resamp_;
     SpectrumCore spec_;
     float2 *d_stage_in_ = nullptr;
     std::vector<float> h_frame_, h_out_;

@@ -54,8 +54,20 @@ int Receiver::create(const pebblegpu_config *cfg)
         if (int rc = am_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_AM(m_inputSampleRate), demod.cpp:62
         // Demod_SAM / Demod_NFM objects also exist in every Receiver (demod.cpp:63-64); their buffers are allocated on first use
         pll_cap_ = nd_max;
+        if (int rc = agc_.init(C, (double)demod_rate_int)) return rc;  // AGC(m_demodSampleRate, m_demodFrames), receiver.cpp:264
     } else {
         if (int rc = wfmc_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_WFM(m_inputWfmSampleRate), demod.cpp:65
+    }
+    audio_rate = cfg->audio_rate;
+    if (audio_rate) {
+        // resampRate = (m_demodSampleRate*1.0) / (m_audioOutRate*1.0), the int members (receiver.cpp:901,994)
+        const double rr = ((double)demod_rate_int * 1.0) / ((double)audio_rate * 1.0);
+        if (rr == 1.0) audio_rate = 0;  // copyCPX branch (receiver.cpp:1002-1003)
+        else {
+            if (int rc = resamp_.init(C, nf, rr, (uint32_t)(nd_max / nf))) return rc;
+            rs_pitch = resamp_.max_out(nd_max);
+            PG_HIP(hipMalloc((void **)&d_audio_rs, sizeof(float2) * (size_t)rs_pitch * C));
+        }
     }
     if (bins) {
         if (int rc = spec_.init(S, nf, bins)) return rc;
@@ -70,6 +82,8 @@ Receiver::~Receiver()
     (void)hipSetDevice(device);
     if (stream_) (void)hipStreamSynchronize(stream_);
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
+    agc_.release(); resamp_.release();
+    if (d_audio_rs) (void)hipFree(d_audio_rs);
     audio.release();
     if (d_spec) (void)hipFree(d_spec);
     if (d_stage_in_) (void)hipFree(d_stage_in_);
@@ -98,6 +112,14 @@ int Receiver::set_mode(uint32_t ch, int mode)
     if (ctl_[ch].mode != mode) am_list_dirty_ = true;
     ctl_[ch].mode = mode;
     return 0;
+}
+
+int Receiver::set_agc(uint32_t ch, int mode, int threshold)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the WFM branch has no AGC (receiver.cpp:854-901)");
+    std::lock_guard<std::mutex> g(mu_);
+    return agc_.set_mode(ch, mode, threshold);
 }
 
 int Receiver::set_bandpass(uint32_t ch, double lo, double hi)
@@ -138,6 +160,7 @@ int Receiver::apply_controls()
             c.am_dirty = false;
         }
     }
+    if (int rc = agc_.apply(stream_)) return rc;
     if (am_list_dirty_) {
         std::vector<int> l, ls, ln;
         for (uint32_t ch = 0; ch < C; ch++) {
@@ -186,6 +209,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (!wfm) {
         if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
         PG_HIP(hipEventRecord(ev[4], stream_));
+        if (int rc = agc_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
         if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
         if (sam_.C) { if (int rc = sam_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
@@ -193,6 +217,12 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     } else {
         PG_HIP(hipEventRecord(ev[4], stream_));
         if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
+    }
+    last_audio_n = (uint64_t)nd;
+    if (audio_rate) {  // CFractResampler::Resample into the audio buffer, receiver.cpp:1000-1001
+        long long n_rs = 0;
+        if (int rc = resamp_.run(stream_, audio.data(), audio.pitch, nd, d_audio_rs, rs_pitch, &n_rs)) return rc;
+        last_audio_n = (uint64_t)n_rs;
     }
     PG_HIP(hipEventRecord(ev[5], stream_));
     {  // one launch refreshes every history head-room for the next call
@@ -203,7 +233,6 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     }
     PG_HIP(hipEventRecord(ev[6], stream_));
     osc_.advance(n);
-    last_audio_n = (uint64_t)nd;
     return 0;
 }
 
@@ -242,7 +271,7 @@ int Receiver::process_iq(const double *iq, uint16_t n, double *audio_out, uint32
         if (int rc = sync()) return rc;
         const size_t na = (size_t)last_audio_n;
         h_out_.resize(na * 2);
-        PG_HIP(hipMemcpy(h_out_.data(), audio.data(0), sizeof(float2) * na, hipMemcpyDeviceToHost));
+        PG_HIP(hipMemcpy(h_out_.data(), audio_ptr(), sizeof(float2) * na, hipMemcpyDeviceToHost));
         if (audio_out)
             for (size_t i = 0; i < na * 2; i++) audio_out[i] = (double)h_out_[i];
         *n_audio = (uint32_t)na;

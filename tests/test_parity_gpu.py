@@ -590,6 +590,79 @@ def test_config5_error_paths(gpu_lib):
     assert e.value.code == -6
 
 
+# ------------------------------------------------------------------------------------------------
+# AGC on the narrow branch, fractional resampler after the demodulator
+# ------------------------------------------------------------------------------------------------
+def test_audio_tail_usb_agc_and_resampler(gpu_lib, oracle_mod):
+    """Two USB channels through AGC (MED / knee 30 on one, manual gain 30 -> +6 dB on the other) and the 28-tap sinc
+    resampler to 11025 Hz, over three calls of 1, 2 and 2 super-frames against the oracle run frame by frame: the
+    output COUNT must match exactly (it comes from the reference's running fp64 time sum) and the samples to 1e-5."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 2
+    ref = [oracle_mod.Receiver(fs, n, 0) for _ in range(C)]
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2, audio_rate=11025)
+    fcs = [-400e3, 300e3]
+    for c in range(C):
+        ref[c].set_mode(oracle_mod.USB); ref[c].set_mixer(fcs[c]); ref[c].set_filter(300, 3000); ref[c].set_audio_rate(11025)
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+    ref[0].set_agc(2, 30); rx.set_agc(0, 2, 30)
+    ref[1].set_agc(0, 30); rx.set_agc(1, 0, 30)
+    sf = rx.superframe
+    t = np.arange(5 * sf) / fs
+    env = 0.02 + 0.3 * (np.sin(2 * np.pi * 2.5 * t) > 0)  # level steps exercise attack, decay and the peak-window rescan
+    x = env * (np.exp(2j * np.pi * (fcs[0] + 1000.0) * t) + np.exp(2j * np.pi * (fcs[1] + 1700.0) * t)) + lcg_noise(5 * sf, 3, 1e-4)
+    g = np.concatenate([rx.process(x[lo:hi])[0] for lo, hi in ((0, sf), (sf, 3 * sf), (3 * sf, 5 * sf))], axis=1)
+    for c in range(C):
+        r = np.concatenate([ref[c].process(x[f * n:(f + 1) * n])[0] for f in range(5 * sf // n)])
+        assert g.shape[1] == len(r)
+        assert rel_rms(g[c], r) <= TOL
+
+
+def test_audio_tail_wfm_resampled(gpu_lib, oracle_mod):
+    """WFM mono resampled to 48 kHz (rate 64000/48000: 1536..1537 outputs per 2048-sample frame), two calls."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    ref = oracle_mod.Receiver(fs, n, 0); ref.set_mode(oracle_mod.FMM); ref.set_mixer(200e3); ref.set_audio_rate(48000)
+    rx = P.ReceiverBank(fs, 1, True, True, 0, max_superframes=3, audio_rate=48000)
+    rx.set_mixer(0, 200e3)
+    sf = rx.superframe
+    t = np.arange(4 * sf) / fs
+    x = 0.5 * np.exp(1j * (2 * np.pi * 200e3 * t + 75.0 * np.sin(2 * np.pi * 1000 * t))) + lcg_noise(4 * sf, 2, 1e-3)
+    g = np.concatenate([rx.process(x[:3 * sf])[0], rx.process(x[3 * sf:])[0]], axis=1)
+    r = np.concatenate([ref.process(x[f * n:(f + 1) * n])[0] for f in range(4 * sf // n)])
+    assert g.shape[1] == len(r)
+    assert rel_rms(g[0], r) <= TOL
+
+
+def test_audio_tail_call_split_invariance_and_host_frames(gpu_lib, oracle_mod):
+    """(a) one 4-super-frame call equals four 1-super-frame calls: identical output counts and sample positions (the
+    resampler's time sum is replayed per frame, as the reference runs it); (b) the host frame path returns the
+    resampled frame counts of the oracle."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    a = P.ReceiverBank(fs, 1, True, False, 0, max_superframes=4, audio_rate=11025)
+    b = P.ReceiverBank(fs, 1, True, False, 0, max_superframes=1, audio_rate=11025)
+    ref = oracle_mod.Receiver(fs, n, 0); ref.set_mode(oracle_mod.USB); ref.set_mixer(100e3); ref.set_filter(300, 3000); ref.set_audio_rate(11025)
+    for rx in (a, b):
+        rx.set_mode(0, P.DM_USB); rx.set_mixer(0, 100e3); rx.set_bandpass(0, 300, 3000)
+    sf = a.superframe
+    t = np.arange(4 * sf) / fs
+    x = (0.3 * (1 + 0.5 * np.sin(2 * np.pi * 700 * t)) * np.exp(2j * np.pi * 101e3 * t)).astype(np.complex64)
+    A = a.process(x)[0]
+    B = np.concatenate([b.process(x[i * sf:(i + 1) * sf])[0] for i in range(4)], axis=1)
+    # same counts; values to the oscillator's phase rounding (phase0 is re-based per call), not bit for bit
+    assert A.shape == B.shape and np.abs(A - B).max() <= 1e-6
+    h = P.ReceiverBank(fs, 1, True, False, 0, max_superframes=1, audio_rate=11025)
+    h.set_mode(0, P.DM_USB); h.set_mixer(0, 100e3); h.set_bandpass(0, 300, 3000)
+    got, want = [], []
+    for f in range(4 * sf // n):
+        au, _ = h.process_iq(x[f * n:(f + 1) * n].astype(np.complex128))
+        ra, _ = ref.process(x[f * n:(f + 1) * n].astype(np.complex128), want_spectrum=False)
+        assert len(au) == len(ra)
+        got.append(au); want.append(ra)
+    assert rel_rms(np.concatenate(got), np.concatenate(want)) <= TOL
+
+
 def test_error_paths(gpu_lib):
     import pebblesdr_amd as P
     rx = P.ReceiverBank(2048000, 2, True, False, 0)
@@ -606,6 +679,13 @@ def test_error_paths(gpu_lib):
     with pytest.raises(P.PebbleGpuError) as e:
         rx.process_device(buf.ptr, 1000)  # not a whole super-frame
     assert e.value.code == -5
+    w = P.ReceiverBank(2048000, 1, True, True, 0)
+    with pytest.raises(P.PebbleGpuError) as e:
+        w.set_agc(0, 2, 30)  # the WFM branch has no AGC step
+    assert e.value.code == -6
+    with pytest.raises(P.PebbleGpuError) as e:
+        rx.set_agc(0, 9, 30)
+    assert e.value.code == -1
     with pytest.raises(P.PebbleGpuError):
         P.ReceiverBank(2048000, 1, True, False, 1 << 16)  # 65536 bins clamps to 65535: not a power of two (fft.cpp:76-77)
 

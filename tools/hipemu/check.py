@@ -175,6 +175,50 @@ def case_receiver():
     return ok
 
 
+def case_audio_tail():
+    """AGC on the narrow branch and the fractional resampler after the demod"""
+    ok = True
+    fs, n = 2048000, 2048
+    # USB bank with AGC MED on channel 0, manual gain on channel 1, resampled to 11025 Hz
+    C = 2
+    ref = [O.Receiver(fs, n, 0) for _ in range(C)]
+    rx = B.ReceiverBank(fs, C, True, False, 0, max_superframes=2, lib=L, audio_rate=11025)
+    fcs = [-400e3, 300e3]
+    for c in range(C):
+        ref[c].set_mode(O.USB); ref[c].set_mixer(fcs[c]); ref[c].set_filter(300, 3000); ref[c].set_audio_rate(11025)
+        rx.set_mode(c, B.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+    ref[0].set_agc(2, 30); rx.set_agc(0, 2, 30)
+    ref[1].set_agc(0, 30); rx.set_agc(1, 0, 30)
+    sf = rx.superframe
+    t = np.arange(5 * sf) / fs
+    env = 0.02 + 0.3 * (np.sin(2 * np.pi * 2.5 * t) > 0)
+    x = env * (np.exp(2j * np.pi * (fcs[0] + 1000.0) * t) + np.exp(2j * np.pi * (fcs[1] + 1700.0) * t)) + lcg_noise(5 * sf, 3, 1e-4)
+    outs = []
+    for lo, hi in ((0, sf), (sf, 3 * sf), (3 * sf, 5 * sf)):
+        a, _ = rx.process(x[lo:hi])
+        outs.append(a)
+    g = np.concatenate(outs, axis=1)
+    for c in range(C):
+        r = np.concatenate([ref[c].process(x[f * n:(f + 1) * n])[0] for f in range(5 * sf // n)])
+        ok &= report("USB + AGC(%s) + resampler channel %d: count %d vs %d" % ("MED" if c == 0 else "OFF/30", c, g.shape[1], len(r)), float(abs(g.shape[1] - len(r))), 0.0)
+        m = min(g.shape[1], len(r))
+        ok &= report("USB + AGC + resampler channel %d" % c, rel_rms(g[c][:m], r[:m]), 1e-5)
+    # WFM resampled to 48 kHz
+    ref = O.Receiver(fs, n, 0); ref.set_mode(O.FMM); ref.set_mixer(200e3); ref.set_audio_rate(48000)
+    rx = B.ReceiverBank(fs, 1, True, True, 0, max_superframes=3, lib=L, audio_rate=48000)
+    rx.set_mixer(0, 200e3)
+    sf = rx.superframe
+    t = np.arange(4 * sf) / fs
+    x = 0.5 * np.exp(1j * (2 * np.pi * 200e3 * t + 75.0 * np.sin(2 * np.pi * 1000 * t))) + lcg_noise(4 * sf, 2, 1e-3)
+    a1, _ = rx.process(x[:3 * sf]); a2, _ = rx.process(x[3 * sf:])
+    g = np.concatenate([a1, a2], axis=1)
+    r = np.concatenate([ref.process(x[f * n:(f + 1) * n])[0] for f in range(4 * sf // n)])
+    ok &= report("WFM + resampler count %d vs %d" % (g.shape[1], len(r)), float(abs(g.shape[1] - len(r))), 0.0)
+    m = min(g.shape[1], len(r))
+    ok &= report("WFM + resampler 48 kHz", rel_rms(g[0][:m], r[:m]), 1e-5)
+    return ok
+
+
 def case_streambank():
     ok = True
     fs, S, N = 2.0e6, 2, 65536
@@ -198,7 +242,7 @@ def case_streambank():
     return ok
 
 
-CASES = {"streambank": case_streambank, "spectrum": case_spectrum, "mixer": case_mixer, "decimator": case_decimator, "fastfir": case_fastfir,
+CASES = {"audio_tail": case_audio_tail, "streambank": case_streambank, "spectrum": case_spectrum, "mixer": case_mixer, "decimator": case_decimator, "fastfir": case_fastfir,
          "demod": case_demod, "receiver": case_receiver}
 
 if __name__ == "__main__":
