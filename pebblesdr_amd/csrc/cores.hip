@@ -310,16 +310,20 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
         if (int rc = buf0.alloc((int)C, (int)halo0, len0)) return rc;
         if (int rc = fin.alloc((int)C, last_hist, len0 / later)) return rc;
     }
-    PG_HIP(hipMalloc((void **)&d_hist_mixed, sizeof(float2) * kMaxTaps * C));
-    PG_HIP(hipMemset(d_hist_mixed, 0, sizeof(float2) * kMaxTaps * C));
+    for (int i = 0; i < 2; i++) {
+        PG_HIP(hipMalloc((void **)&d_hist_mixed[i], sizeof(float2) * kMaxTaps * C));
+        PG_HIP(hipMemset(d_hist_mixed[i], 0, sizeof(float2) * kMaxTaps * C));
+    }
     return 0;
 }
 void DecimCore::release()
 {
     buf0.release();
     fin.release();
-    if (d_hist_mixed) (void)hipFree(d_hist_mixed);
-    d_hist_mixed = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (d_hist_mixed[i]) (void)hipFree(d_hist_mixed[i]);
+        d_hist_mixed[i] = nullptr;
+    }
 }
 int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
                    hipEvent_t after_first)
@@ -329,9 +333,9 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     len0 = n / first.stride;
     if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
     launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), C), dim3(256), mixdec_lds_bytes(first), s, d_in, in_pitch, (int)shared_input, buf0.data(),
-               buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed, (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, first);
-    launch(k_mix_tail, dim3(C), dim3(64), s, d_in, in_pitch, (int)shared_input, n, (const ChanOsc *)osc.d_osc, d_hist_mixed, (int)kMaxTaps,
-           (const float *)osc.d_amp, osc.a_inf, first.ntaps, first.stride, first.cic3);
+               buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], (int)kMaxTaps, (const float *)osc.d_amp,
+               osc.a_inf, first, d_hist_mixed[hist_parity ^ 1]);  // its last block leaves the next call's mixed history
+    hist_parity ^= 1;
     if (after_first) PG_HIP(hipEventRecord(after_first, s));
     len_out = len0;
     if (casc.nst > 0) {
@@ -344,8 +348,8 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
 }
 void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
-    if (buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0});
-    if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0});
+    if (buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
+    if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
 }
 
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels)
@@ -574,7 +578,7 @@ int PllCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
            (const float *)d_taps_q, 0, (const int *)nullptr, ntaps, 1.0f, mode == 1 ? 1 : 0, (const int *)d_list);
     std::vector<TailJob> jobs;
     // listed channels only would need a list-aware tail kernel; refreshing every row is harmless (idle rows keep zeros)
-    jobs.push_back(TailJob{tmp.data(), tmp.pitch, n, tmp.hist, 0});
+    jobs.push_back(TailJob{tmp.data(), tmp.pitch, n, tmp.hist, 0, nullptr, 0});
     return run_save_tails(s, jobs, C);
 }
 
@@ -661,10 +665,13 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(256), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
                    out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp);
         PG_HIP(hipGetLastError());
-        // next call's history = the last Lx samples of (old history | this call's input), into the other buffer
+        // next call's history = the last Lx samples of (old history | this call's input), into the other buffer; when the
+        // call alone covers it the copy rides on the caller's tail-refresh launch (tail_jobs)
         float2 *nt = d_xtail[parity ^ 1];
+        deferred_in = nullptr;
         if (n >= Lx) {
-            PG_HIP(hipMemcpy2DAsync(nt, sizeof(float2) * Lx, in + (n - Lx), sizeof(float2) * in_pitch, sizeof(float2) * Lx, C, hipMemcpyDeviceToDevice, s));
+            deferred_in = in;
+            deferred_pitch = in_pitch;
         } else {
             PG_HIP(hipMemcpy2DAsync(nt, sizeof(float2) * Lx, d_xtail[parity] + n, sizeof(float2) * Lx, sizeof(float2) * (Lx - n), C, hipMemcpyDeviceToDevice, s));
             PG_HIP(hipMemcpy2DAsync(nt + (Lx - n), sizeof(float2) * Lx, in, sizeof(float2) * in_pitch, sizeof(float2) * n, C, hipMemcpyDeviceToDevice, s));
@@ -690,9 +697,12 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
 }
 void WfmCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
-    if (fused) return;
-    jobs.push_back(TailJob{a.data(), a.pitch, last_n, a.hist, 0});
-    jobs.push_back(TailJob{b.data(), b.pitch, last_n, b.hist, 0});
+    if (fused) {
+        if (deferred_in) jobs.push_back(TailJob{const_cast<float2 *>(deferred_in), deferred_pitch, last_n, L4 + Llp, 0, d_xtail[parity], (long long)(L4 + Llp)});
+        return;
+    }
+    jobs.push_back(TailJob{a.data(), a.pitch, last_n, a.hist, 0, nullptr, 0});
+    jobs.push_back(TailJob{b.data(), b.pitch, last_n, b.hist, 0, nullptr, 0});
 }
 
 // ------------------------------------------------------------------------------------------------

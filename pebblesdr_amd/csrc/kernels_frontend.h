@@ -58,7 +58,7 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
                                                           float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                           const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
                                                           int hist_pitch, const float *__restrict__ amp_tab, float a_inf,
-                                                          FirTaps taps)
+                                                          FirTaps taps, float2 *__restrict__ hist_out)
 {
     HIP_DYNAMIC_SHARED(float2, tile)
     __shared__ float ht[kMaxTaps];  // taps out of the kernel-argument segment: the tap loop must not wait on scalar loads
@@ -109,6 +109,16 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
         tile[s0 + 1 + ((s0 + 1) >> ls)] = b;
     }
     __syncthreads();
+    // The block that reaches the end of the call leaves the mixed-sample history for the next one in the OTHER history
+    // buffer (block 0 of this launch may still be reading `hist`): hist_out[c][j] = m[n - H + j], the tile's last H slots
+    // (for CIC3 the pair m[n-S], m[n-S+1]).
+    if (hist_out != nullptr && o0 + nout == n_out) {
+        const int Hh = taps.cic3 ? 2 : T - 1;
+        if (t < Hh) {
+            const int sl = taps.cic3 ? span - S + t : span - Hh + t;
+            hist_out[(long long)c * hist_pitch + t] = tile[sl + (sl >> ls)];
+        }
+    }
     if (t >= nout) return;
     float2 acc;
     if (taps.cic3) {
@@ -190,32 +200,6 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
             dst = tmp;
         }
     }
-}
-
-// Mixed-sample history for the next call: hist[c][j] = m[n - H + j], j < H (H = T-1, or for CIC3
-// the pair m[n-S], m[n-S+1]).  grid (C), block 64.  Runs after k_mix_dec1 of the same call.
-static __global__ __launch_bounds__(64) void k_mix_tail(const float2 *__restrict__ in, long long in_pitch, int shared_input,
-                                                  long long n, const ChanOsc *__restrict__ osc, float2 *__restrict__ hist,
-                                                  int hist_pitch, const float *__restrict__ amp_tab, float a_inf,
-                                                  int ntaps, int stride, int cic3)
-{
-    const int c = blockIdx.x, j = threadIdx.x;
-    const ChanOsc *oc = &osc[c];
-    const float2 *x = in + (shared_input ? 0 : (long long)c * in_pitch);
-    long long i;
-    if (cic3) {
-        if (j >= 2) return;
-        i = n - stride + j;
-    } else {
-        if (j >= ntaps - 1) return;
-        i = n - (ntaps - 1) + j;
-    }
-    float2 m = x[i];
-    if (oc->mix_on) {
-        const float2 ph = cis_cycles(oc->phase0 + (double)(i + 1) * oc->inc);
-        m = cmul(cscale(ph, osc_amp(amp_tab, a_inf, oc->n0, i)), m);
-    }
-    hist[(long long)c * hist_pitch + j] = m;
 }
 
 // Generic real-tap FIR on complex data with decimation: the CFir post-demod filters (stride 1) and any stand-alone
@@ -329,7 +313,10 @@ static __global__ __launch_bounds__(256) void k_save_tails(TailJobs jobs)
 #pragma unroll
     for (int k = 0; k < 32; k++) {
         const int j = threadIdx.x + 256 * k;
-        if (j < tj.hist) b[-tj.hist + j] = keep[k];
+        if (j < tj.hist) {
+            if (tj.dst) tj.dst[(long long)blockIdx.y * tj.dst_pitch + j] = keep[k];
+            else b[-tj.hist + j] = keep[k];
+        }
     }
 }
 

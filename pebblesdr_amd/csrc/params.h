@@ -64,11 +64,14 @@ struct PllState {             // per channel
     double dc_re_last, dc_im_last;  // SAM DC removal (doubles, demod_sam.h:27-31)
 };
 
-// history-tail refresh jobs: buf[c][-hist + j] = buf[c][n - hist + j] for every channel c (one launch for all buffers)
+// history-tail refresh jobs, one launch for all buffers: for every channel c, dst[c][j] = data[c][n - hist + j], j < hist,
+// where dst is the buffer's own head-room (data[c][-hist + j]) unless a separate history buffer is given
 struct TailJob {
     float2 *data;
     long long pitch, n;
     int hist, pad_;
+    float2 *dst;           // nullptr: the head-room in front of data
+    long long dst_pitch;
 };
 constexpr int kMaxTailJobs = 12;
 struct TailJobs {

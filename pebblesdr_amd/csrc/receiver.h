@@ -67,7 +67,8 @@ struct DecimCore {
     size_t casc_lds_bytes = 0;
     HistBuf buf0, fin;               // stage-0 output (head-room = cascade look-back), final output (absent for 1-stage chains)
     long long len0 = 0, len_out = 0; // lengths produced by the last run
-    float2 *d_hist_mixed = nullptr;  // [C][kMaxTaps]: mixed-sample history of stage 0
+    float2 *d_hist_mixed[2] = {nullptr, nullptr};  // [C][kMaxTaps]: mixed-sample history of stage 0 (read one, write the other)
+    int hist_parity = 0;
     // last_hist: head-room of the final buffer (what the consumer looks back at); last_gain: folded into the final stage
     int init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain);
     void release();
@@ -146,6 +147,8 @@ struct WfmCore {
     float *d_h = nullptr;           // [L4 + 16]
     float *d_hlp = nullptr;         // [Llp]
     float2 *d_xtail[2] = {nullptr, nullptr};  // [C][L4 + Llp] input history, ping-pong
+    const float2 *deferred_in = nullptr;      // set by run(): the history copy is left to tail_jobs()
+    long long deferred_pitch = 0;
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
