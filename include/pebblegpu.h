@@ -155,6 +155,9 @@ const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *
  * call; 1 spectrum kernel; 2 mixer+first-decimator kernel; 3 remaining decimator stages; 4 FastFIR;
  * 5 demod. */
 int pebblegpu_receiver_last_ms(const pebblegpu_receiver *rx, int which, float *ms);
+/* which 0 and 1 are always available (three event records per call).  The per-kernel splits 2..5 need four more
+ * records, each a ~5 us bubble in the stream, so they are recorded only after set_profiling(rx, 1). */
+int pebblegpu_receiver_set_profiling(pebblegpu_receiver *rx, int per_kernel);
 /* the same, averaged over the last `last_k` process calls (the library keeps events for 64): lets a caller queue calls
  * back to back without a host sync per call and read the kernel times afterwards */
 int pebblegpu_receiver_mean_ms(const pebblegpu_receiver *rx, int which, uint32_t last_k, float *ms);

@@ -177,6 +177,16 @@ int OscBank::upload(hipStream_t s)
         hd[ch].n0 = (uint32_t)(ctl[ch].n0 > (uint64_t)kAmpTab ? (uint64_t)kAmpTab : ctl[ch].n0);
         hd[ch].mix_on = h_osc[ch].mix_on;
     }
+    inline_dyn.use = 0;
+    if (allow_inline && C <= (uint32_t)kOscInline) {  // small bank: the consumer takes these 16 bytes per channel as kernel arguments
+        for (uint32_t ch = 0; ch < C; ch++) {
+            inline_dyn.d[ch].phase0 = hd[ch].phase0;
+            inline_dyn.d[ch].n0 = hd[ch].n0;
+            inline_dyn.d[ch].mix_on = hd[ch].mix_on;
+        }
+        inline_dyn.use = 1;
+        return 0;
+    }
     PG_HIP(hipMemcpy2DAsync(d_osc, sizeof(ChanOsc), hd, sizeof(Dyn), sizeof(Dyn), C, hipMemcpyHostToDevice, s));
     PG_HIP(hipEventRecord(h_done[cur], s));
     return 0;
@@ -334,7 +344,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
     launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), C), dim3(256), mixdec_lds_bytes(first), s, d_in, in_pitch, (int)shared_input, buf0.data(),
                buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], (int)kMaxTaps, (const float *)osc.d_amp,
-               osc.a_inf, first, d_hist_mixed[hist_parity ^ 1]);  // its last block leaves the next call's mixed history
+               osc.a_inf, first, d_hist_mixed[hist_parity ^ 1], osc.inline_dyn);  // its last block leaves the next call's mixed history
     hist_parity ^= 1;
     if (after_first) PG_HIP(hipEventRecord(after_first, s));
     len_out = len0;

@@ -58,7 +58,7 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
                                                           float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                           const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
                                                           int hist_pitch, const float *__restrict__ amp_tab, float a_inf,
-                                                          FirTaps taps, float2 *__restrict__ hist_out)
+                                                          FirTaps taps, float2 *__restrict__ hist_out, OscDynInline dyn)
 {
     HIP_DYNAMIC_SHARED(float2, tile)
     __shared__ float ht[kMaxTaps];  // taps out of the kernel-argument segment: the tap loop must not wait on scalar loads
@@ -74,8 +74,10 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
     const int nout = (int)((n_out - o0) < 256 ? (n_out - o0) : 256);
     const long long i0 = o0 * S - H;                  // input index of tile slot 0 (even)
     const int span = nout * S + H;                    // even
-    const bool mix = oc->mix_on != 0;
-    const bool settled = oc->n0 >= (uint32_t)kAmpTab; // amplitude transient over: a_n == sqrt(0.95) to fp32
+    const double phase0 = dyn.use ? dyn.d[c].phase0 : oc->phase0;
+    const uint32_t n0 = dyn.use ? dyn.d[c].n0 : oc->n0;
+    const bool mix = (dyn.use ? dyn.d[c].mix_on : oc->mix_on) != 0;
+    const bool settled = n0 >= (uint32_t)kAmpTab; // amplitude transient over: a_n == sqrt(0.95) to fp32
     float2 ph = make_float2(1.f, 0.f);
     int sweep = 0;
     for (int v = t; v < span / 2; v += 256, sweep++) {
@@ -95,11 +97,11 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
             a = make_float2(xx.x, xx.y);
             b = make_float2(xx.z, xx.w);
             if (mix) {
-                if ((sweep & 3) == 0) ph = cis_cycles(oc->phase0 + (double)(i + 1) * oc->inc);
+                if ((sweep & 3) == 0) ph = cis_cycles(phase0 + (double)(i + 1) * oc->inc);
                 else ph = cmul(ph, oc->step512);
                 const float2 ph1 = cmul(ph, oc->step[1]);
-                const float aa = settled ? a_inf : osc_amp(amp_tab, a_inf, oc->n0, i);
-                const float ab = settled ? a_inf : osc_amp(amp_tab, a_inf, oc->n0, i + 1);
+                const float aa = settled ? a_inf : osc_amp(amp_tab, a_inf, n0, i);
+                const float ab = settled ? a_inf : osc_amp(amp_tab, a_inf, n0, i + 1);
                 a = cmul(cscale(ph, aa), a);
                 b = cmul(cscale(ph1, ab), b);
             }

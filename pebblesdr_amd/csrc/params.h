@@ -38,6 +38,14 @@ struct CascadeParams {
 };
 
 constexpr size_t kChanOscDynBytes = 16;
+// The per-call part of ChanOsc for small banks travels in the kernel arguments instead of a host-to-device copy in the
+// stream (which costs a ~10 us bubble per call); use == 0: read it from the ChanOsc block.
+constexpr int kOscInline = 8;
+struct OscDyn { double phase0; uint32_t n0, mix_on; };
+struct OscDynInline {
+    OscDyn d[kOscInline];
+    int use, pad_;
+};
 
 constexpr int kSeg = 8;               // consecutive samples one lane runs serially
 constexpr int kSub = 64 * kSeg;       // samples one wave scans at a time

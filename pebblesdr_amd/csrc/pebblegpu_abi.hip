@@ -186,12 +186,20 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
     double sum = 0;
     for (uint32_t k = 0; k < last_k; k++) {
         const hipEvent_t *ev = t.ev[(t.calls - 1 - k) % pg::Timers::kRing];
+        if (which >= 2 && !t.detailed[(t.calls - 1 - k) % pg::Timers::kRing])
+            return fail(PEBBLEGPU_E_INVALID, "per-kernel times need pebblegpu_receiver_set_profiling(rx, 1) before the calls");
         float one = 0;
         PG_HIP(hipEventSynchronize(ev[6]));
         PG_HIP(hipEventElapsedTime(&one, ev[a[which]], ev[b[which]]));
         sum += one;
     }
     *ms = (float)(sum / last_k);
+    return 0;
+}
+int pebblegpu_receiver_set_profiling(pebblegpu_receiver *h, int per_kernel)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    h->rx.profile_detail = per_kernel != 0;
     return 0;
 }
 int pebblegpu_receiver_last_ms(const pebblegpu_receiver *h, int which, float *ms) { return kernel_ms(h, which, 1, ms); }

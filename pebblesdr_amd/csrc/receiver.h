@@ -45,6 +45,8 @@ struct OscBank {
     std::vector<Ctl> ctl;
     std::vector<ChanOsc> h_osc;               // host master copy
     struct Dyn { double phase0; uint32_t n0, mix_on; };
+    OscDynInline inline_dyn = {};             // filled by upload() when allow_inline and C <= kOscInline
+    bool allow_inline = false;                // set by owners whose kernels take OscDynInline
     Dyn *h_dyn[2] = {nullptr, nullptr};       // pinned staging of the per-call fields, ping-pong: no host sync per call
     hipEvent_t h_done[2] = {nullptr, nullptr};
     int h_idx = 0;
@@ -212,6 +214,7 @@ struct SpectrumCore {
 struct Timers {
     static constexpr int kRing = 64;
     hipEvent_t ev[kRing][8] = {};
+    bool detailed[kRing] = {};   // per-kernel events (2..5) were recorded for that call
     uint64_t calls = 0;
     hipEvent_t *slot() { return ev[calls % kRing]; }
 };
@@ -239,6 +242,7 @@ public:
     Timers tm;
     HistBuf audio;   // [C][k*nf]
     float *d_spec = nullptr;
+    bool profile_detail = false;      // record the per-kernel events too (pebblegpu_receiver_set_profiling)
     uint32_t audio_rate = 0;          // 0: audio stays at the demod rate (the resampRate == 1 branch, receiver.cpp:1000-1003)
     float2 *d_audio_rs = nullptr;     // [C][rs_pitch] resampled audio
     long long rs_pitch = 0;

@@ -45,6 +45,7 @@ int Receiver::create(const pebblegpu_config *cfg)
     ctl_.assign(C, ChanCtl());
     for (auto &c : ctl_) c.mode = wfm ? PEBBLEGPU_DM_FMM : PEBBLEGPU_DM_AM;  // Demod ctor default dmAM, demod.cpp:56
     if (int rc = osc_.init(C, fs)) return rc;
+    osc_.allow_inline = true;
     // "Restore gain lost in decimation" 10^(2*stages/20) only on the narrow branch (receiver.cpp:935-938 vs :854-901)
     const float gain = wfm ? 1.f : (float)std::pow(10.0, (double)(chain.dec_by2 * 2) / 20.0);
     if (int rc = dec_.init(C, chain, max_n, wfm ? 0 : (int)ff_taps - 1, gain)) return rc;
@@ -198,24 +199,27 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         last_spec_frames = n / nf;
     }
     PG_HIP(hipEventRecord(ev[1], stream_));
+    tm.detailed[(tm.calls - 1) % Timers::kRing] = profile_detail;
     if (!with_chain) {
-        for (int i = 2; i <= 6; i++) PG_HIP(hipEventRecord(ev[i], stream_));
+        if (profile_detail) for (int i = 2; i <= 5; i++) PG_HIP(hipEventRecord(ev[i], stream_));
+        PG_HIP(hipEventRecord(ev[6], stream_));
         return 0;
     }
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
-    if (int rc = dec_.run(stream_, d_iq, in_pitch, shared_input, (long long)n, osc_, ev[2])) return rc;
-    PG_HIP(hipEventRecord(ev[3], stream_));
+    // an event record costs the stream a ~5 us bubble: per-kernel events only when asked for (set_profiling)
+    if (int rc = dec_.run(stream_, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr)) return rc;
+    if (profile_detail) PG_HIP(hipEventRecord(ev[3], stream_));
     const long long nd = dec_.out_len();
     if (!wfm) {
         if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
-        PG_HIP(hipEventRecord(ev[4], stream_));
+        if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
         if (int rc = agc_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
         if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
         if (sam_.C) { if (int rc = sam_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
         if (nfm_.C) { if (int rc = nfm_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
     } else {
-        PG_HIP(hipEventRecord(ev[4], stream_));
+        if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
         if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
     }
     last_audio_n = (uint64_t)nd;
@@ -224,7 +228,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (int rc = resamp_.run(stream_, audio.data(), audio.pitch, nd, d_audio_rs, rs_pitch, &n_rs)) return rc;
         last_audio_n = (uint64_t)n_rs;
     }
-    PG_HIP(hipEventRecord(ev[5], stream_));
+    if (profile_detail) PG_HIP(hipEventRecord(ev[5], stream_));
     {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
