@@ -193,7 +193,23 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
     }
     const float2 *x = in + (long long)c * in_pitch + first;
     float2 *src = buf, *dst = buf + cp.lds_half;
-    for (int j = t; j < cnt[0]; j += 256) src[j] = x[j];
+    // all of this tile's loads in flight together (as in k_mix_dec1): batches of kBatch, issued before any LDS store
+    {
+        constexpr int kBatch = 6;
+        for (int jb = t; jb < cnt[0]; jb += 256 * kBatch) {
+            float2 v[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int j = jb + 256 * k;
+                v[k] = j < cnt[0] ? x[j] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int j = jb + 256 * k;
+                if (j < cnt[0]) src[j] = v[k];
+            }
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < kMaxCascade; s++) {
