@@ -161,6 +161,13 @@ int pebblegpu_receiver_set_profiling(pebblegpu_receiver *rx, int per_kernel);
 /* the same, averaged over the last `last_k` process calls (the library keeps events for 64): lets a caller queue calls
  * back to back without a host sync per call and read the kernel times afterwards */
 int pebblegpu_receiver_mean_ms(const pebblegpu_receiver *rx, int which, uint32_t last_k, float *ms);
+/* S-meter: SignalStrength::fdEstimate (application/signalstrength.cpp:287-380; receiver.cpp:891-892, 959-960) on every
+ * frame's unprocessed spectrum, per channel: float4 (peakDb, avgDb, snrDb, floorDb) at [channel * pitch + frame].  The
+ * band window is the channel's band-pass (+-100 kHz in a WFM bank) around its mixer frequency.  avgDb is the value the
+ * reference's squelch compares with m_squelchDb (receiver.cpp:893-897, 962-965); the gate itself stays with the host.
+ * Needs spectrum_bins != 0.  The reference's 10-per-second update timer is forced open: every frame is measured. */
+int pebblegpu_receiver_enable_signal_strength(pebblegpu_receiver *rx, int on);
+const void *pebblegpu_receiver_signal_strength(const pebblegpu_receiver *rx, uint64_t *frames, uint64_t *pitch_frames);
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);
 
 /* Host single-frame path with the reference's callback shape:

@@ -74,6 +74,8 @@ def lib():
         L.po_receiver_process.argtypes = [C.c_void_p, _dp, C.c_uint32, _dp, _dp]
         L.po_receiver_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.po_receiver_set_audio_rate.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_fd_estimate.restype = C.c_double
+        L.po_fd_estimate.argtypes = [_dp, C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_double, _dp]
         L.po_agc_new.restype = C.c_void_p
         L.po_agc_new.argtypes = [C.c_double]
         L.po_agc_free.argtypes = [C.c_void_p]
@@ -385,6 +387,14 @@ class DemodWFM:
         out = np.empty_like(x)
         lib().po_demod_wfm_process_mono(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
         return out
+
+
+def fd_estimate(spectrum_db, spectrum_rate, bp_lo, bp_hi, mixer_freq):
+    """SignalStrength::fdEstimate -> (peakDb, avgDb, snrDb, floorDb)"""
+    sp = np.ascontiguousarray(spectrum_db, dtype=np.float64)
+    out = np.empty(4, dtype=np.float64)
+    lib().po_fd_estimate(_ptr(sp), len(sp), int(spectrum_rate), float(bp_lo), float(bp_hi), float(mixer_freq), _ptr(out))
+    return out
 
 
 class Agc:

@@ -900,6 +900,48 @@ int po_resampler_process(po_resampler *r, int n, double rate, const double *in, 
     return outsamples;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * SignalStrength::fdEstimate -- application/signalstrength.cpp:287-380, pebblelib/db.h
+ * ---------------------------------------------------------------------------------------------- */
+static int po_qbound(int lo, int v, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static double po_power_to_db(double p) { return p == 0 ? -120.0 : 10 * log10(p); } /* DB::minDb = -120 (db.cpp) */
+static double po_db_clip(double db) { return db < -120.0 ? -120.0 : (db > 0.0 ? 0.0 : db); }
+
+double po_fd_estimate(const double *spectrum, int bins, uint32_t rate, float bp_lo, float bp_hi, double mixer_freq, double *out)
+{
+    double peak_pwr = 0, total = 0, noise_total = 0;
+    const double bin_width = rate / (uint32_t)bins; /* integer division, then widened */
+    const int center = bins / 2;
+    int mixer_bin = (int)(center + (mixer_freq / bin_width));
+    mixer_bin = po_qbound(0, mixer_bin, bins);
+    int lo_bin = (int)(mixer_bin + (bp_lo / bin_width));
+    lo_bin = po_qbound(0, lo_bin, bins);
+    int hi_bin = (int)(mixer_bin + (bp_hi / bin_width));
+    hi_bin = po_qbound(0, hi_bin, bins);
+    const int bp_bins = hi_bin - lo_bin;
+    const int nlo = po_qbound(0, lo_bin - bp_bins, bins), nhi = po_qbound(0, hi_bin + bp_bins, bins);
+    int noise_bins = 0;
+    for (int i = 0; i < bins; i++) {
+        if (i < nlo) continue;
+        const double pwr = pow(10, spectrum[i] / 10.0);
+        if (i >= lo_bin && i <= hi_bin) {
+            total += pwr;
+            if (pwr > peak_pwr) peak_pwr = pwr;
+        } else if (i >= nlo && i <= nhi) {
+            noise_total += pwr;
+            noise_bins++;
+        }
+        if (i >= nhi) break;
+    }
+    const double avg_pwr = total / bp_bins, noise_avg = noise_total / noise_bins;
+    const double peak_db = po_db_clip(po_power_to_db(peak_pwr)), avg_db = po_db_clip(po_power_to_db(avg_pwr));
+    const double floor_db = po_db_clip(po_power_to_db(noise_avg));
+    double snr = (noise_avg == 0 || peak_pwr == 0) ? -120.0 : 10.0 * log10(peak_pwr / noise_avg);
+    snr = snr < 0.0 ? 0.0 : (snr > 120.0 ? 120.0 : snr);
+    if (out) { out[0] = peak_db; out[1] = avg_db; out[2] = snr; out[3] = floor_db; }
+    return avg_db;
+}
+
 struct po_receiver {
     uint32_t fs, n;
     int mode;

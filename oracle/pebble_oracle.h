@@ -158,6 +158,10 @@ void po_resampler_free(po_resampler *r);
 int po_resampler_process(po_resampler *r, int n, double rate, const double *in, double *out);
 double po_resampler_time(const po_resampler *r);              /* m_FloatTime, for tests */
 
+/* SignalStrength::fdEstimate (application/signalstrength.cpp:287-380) on one dB spectrum, update-timer gate forced
+ * open.  out[4] = peakDb, avgDb, snrDb, floorDb.  Returns avgDb.  Integer bin width (quint32 / int) as written. */
+double po_fd_estimate(const double *spectrum, int bins, uint32_t spectrum_rate, float bp_lo, float bp_hi, double mixer_freq, double *out);
+
 typedef struct po_receiver po_receiver;
 po_receiver *po_receiver_new(uint32_t fs, uint32_t frames_per_buffer, uint32_t spectrum_bins,
                              uint32_t fastfir_fft, uint32_t fastfir_taps);

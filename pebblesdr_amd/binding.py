@@ -17,7 +17,7 @@ SYMBOLS = [
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
-    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
+    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
     "pebblegpu_streambank_process", "pebblegpu_streambank_filtered", "pebblegpu_streambank_spectrum",
     "pebblegpu_streambank_last_ms", "pebblegpu_streambank_synchronize",
@@ -98,6 +98,9 @@ def _declare(L):
     L.pebblegpu_receiver_last_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_mean_ms.argtypes = [vp, i32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_set_profiling.argtypes = [vp, i32]
+    L.pebblegpu_receiver_enable_signal_strength.argtypes = [vp, i32]
+    L.pebblegpu_receiver_signal_strength.restype = vp
+    L.pebblegpu_receiver_signal_strength.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.pebblegpu_receiver_synchronize.argtypes = [vp]
     L.pebblegpu_process_iq.argtypes = [vp, dp, C.c_uint16, dp, C.POINTER(u32), dp]
     L.pebblegpu_streambank_create.argtypes = [C.POINTER(StreamBankConfig), C.POINTER(vp)]
@@ -291,6 +294,19 @@ class ReceiverBank:
 
     def synchronize(self):
         check(self.L, self.L.pebblegpu_receiver_synchronize(self.h))
+
+    def enable_signal_strength(self, on=True):
+        check(self.L, self.L.pebblegpu_receiver_enable_signal_strength(self.h, 1 if on else 0))
+
+    def signal_strength(self):
+        """-> float32 [C, frames, 4] = (peakDb, avgDb, snrDb, floorDb) of the last call"""
+        f, pitch = C.c_uint64(), C.c_uint64()
+        p = self.L.pebblegpu_receiver_signal_strength(self.h, C.byref(f), C.byref(pitch))
+        self.synchronize()
+        out = np.empty((self.n_channels, int(f.value), 4), dtype=np.float32)
+        for c in range(self.n_channels):
+            check(self.L, self.L.pebblegpu_memcpy_d2h(self.device, out[c].ctypes.data_as(C.c_void_p), C.c_void_p(p + c * int(pitch.value) * 16), out[c].nbytes))
+        return out
 
     def set_profiling(self, per_kernel=True):
         check(self.L, self.L.pebblegpu_receiver_set_profiling(self.h, 1 if per_kernel else 0))

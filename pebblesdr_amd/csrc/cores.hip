@@ -715,6 +715,15 @@ void WfmCore::tail_jobs(std::vector<TailJob> &jobs) const
     jobs.push_back(TailJob{b.data(), b.pitch, last_n, b.hist, 0, nullptr, 0});
 }
 
+int run_signal_strength(hipStream_t s, const float *d_spec, long long stream_pitch, int bins, long long n_frames, const SmBins *d_bins,
+                        float4 *d_out, long long out_pitch, uint32_t channels)
+{
+    if (n_frames <= 0) return 0;
+    launch(k_signal_strength, dim3((unsigned)n_frames, channels), dim3(64), s, d_spec, stream_pitch, bins, n_frames, d_bins, d_out, out_pitch);
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // AgcCore
 // ------------------------------------------------------------------------------------------------

@@ -281,4 +281,48 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SignalStrength::fdEstimate (application/signalstrength.cpp:287-380) on every frame of the unprocessed spectrum: peak and
+// average power inside the band-pass window around the mixer frequency, average power of one window width either side
+// (noise), all from the dB bins (power = 10^(dB/10)).  One wave per (frame, channel); out[channel][frame] =
+// (peakDb, avgDb, snrDb, floorDb).  The bin indices come from the host (integer bin width etc. as the reference has it).
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(64) void k_signal_strength(const float *__restrict__ spec, long long stream_pitch, int bins, long long n_frames,
+                                                               const SmBins *__restrict__ sb, float4 *__restrict__ out, long long out_pitch)
+{
+    const int c = blockIdx.y, lane = threadIdx.x;
+    const long long f = blockIdx.x;
+    const SmBins b = sb[c];
+    const float *sp = spec + (long long)b.stream * stream_pitch + f * bins;
+    double peak = 0.0, total = 0.0, noise = 0.0;
+    int nn = 0;
+    const int last = b.nhi < bins - 1 ? b.nhi : bins - 1;  // the reference's loop ends at i == noiseHighBin or the last bin
+    for (int i = b.nlo + lane; i <= last; i += 64) {
+        const double pwr = exp2((double)sp[i] * 0.33219280948873623479);  // 10^(dB/10)
+        if (i >= b.lo && i <= b.hi) {
+            total += pwr;
+            peak = pwr > peak ? pwr : peak;
+        } else {
+            noise += pwr;
+            nn++;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double p2 = __shfl_xor(peak, d), t2 = __shfl_xor(total, d), n2 = __shfl_xor(noise, d);
+        const int c2 = __shfl_xor(nn, d);
+        peak = p2 > peak ? p2 : peak;
+        total += t2;
+        noise += n2;
+        nn += c2;
+    }
+    if (lane != 0) return;
+    auto p2db = [](double p) { return p == 0.0 ? -120.0 : 10.0 * log10(p); };
+    auto clip = [](double d) { return d < -120.0 ? -120.0 : (d > 0.0 ? 0.0 : d); };
+    const double avg = total / (double)b.bp_bins, navg = noise / (double)nn;
+    double snr = (navg == 0.0 || peak == 0.0) ? -120.0 : 10.0 * log10(peak / navg);
+    snr = snr < 0.0 ? 0.0 : (snr > 120.0 ? 120.0 : snr);
+    out[(long long)c * out_pitch + f] = make_float4((float)clip(p2db(peak)), (float)clip(p2db(avg)), (float)snr, (float)clip(p2db(navg)));
+}
+
 }  // namespace pg

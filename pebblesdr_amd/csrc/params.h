@@ -87,6 +87,9 @@ struct TailJobs {
     TailJob job[kMaxTailJobs];
 };
 
+// fdEstimate's bin windows for one channel: noise [nlo, nhi] around the band-pass [lo, hi]; stream = which spectrum it reads
+struct SmBins { int nlo, lo, hi, nhi, bp_bins, stream, pad_[2]; };
+
 struct SpectrumParams {
     long long in_pitch;      // samples between streams
     long long n_frames;      // frames in this call (per stream)

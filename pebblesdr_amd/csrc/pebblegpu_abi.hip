@@ -168,6 +168,18 @@ const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *h, uint64_t *f
     if (frames_per_stream) *frames_per_stream = h->rx.last_spec_frames;
     return h->rx.d_spec;
 }
+int pebblegpu_receiver_enable_signal_strength(pebblegpu_receiver *h, int on)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.enable_smeter(on != 0);
+}
+const void *pebblegpu_receiver_signal_strength(const pebblegpu_receiver *h, uint64_t *frames, uint64_t *pitch_frames)
+{
+    if (!h || !h->rx.smeter_on) return nullptr;
+    if (frames) *frames = h->rx.last_spec_frames;
+    if (pitch_frames) *pitch_frames = (uint64_t)h->rx.smeter_pitch;
+    return h->rx.d_smeter;
+}
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *h)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");

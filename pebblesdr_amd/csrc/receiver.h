@@ -36,6 +36,8 @@ void fill_scan_section(ScanSection &s, int type, const double *c);
 int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
+int run_signal_strength(hipStream_t s, const float *d_spec, long long stream_pitch, int bins, long long n_frames, const SmBins *d_bins,
+                        float4 *d_out, long long out_pitch, uint32_t channels);
 
 // ---- oscillator bank (Mixer state for C channels) ----
 struct OscBank {
@@ -242,6 +244,12 @@ public:
     Timers tm;
     HistBuf audio;   // [C][k*nf]
     float *d_spec = nullptr;
+    // SignalStrength::fdEstimate per frame (S-meter): enabled on request, needs the spectrum
+    bool smeter_on = false;
+    float4 *d_smeter = nullptr;       // [C][max frames]
+    SmBins *d_sm_bins = nullptr;
+    long long smeter_pitch = 0;
+    int enable_smeter(bool on);
     bool profile_detail = false;      // record the per-kernel events too (pebblegpu_receiver_set_profiling)
     uint32_t audio_rate = 0;          // 0: audio stays at the demod rate (the resampRate == 1 branch, receiver.cpp:1000-1003)
     float2 *d_audio_rs = nullptr;     // [C][rs_pitch] resampled audio
@@ -259,7 +267,7 @@ private:
     std::mutex mu_;
     hipStream_t stream_ = nullptr;
     std::vector<ChanCtl> ctl_;
-    bool am_list_dirty_ = true;
+    bool am_list_dirty_ = true, sm_dirty_ = true;
     long long pll_cap_ = 0;
     OscBank osc_;
     DecimCore dec_;

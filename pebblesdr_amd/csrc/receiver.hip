@@ -85,6 +85,8 @@ Receiver::~Receiver()
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
     agc_.release(); resamp_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
+    if (d_smeter) (void)hipFree(d_smeter);
+    if (d_sm_bins) (void)hipFree(d_sm_bins);
     audio.release();
     if (d_spec) (void)hipFree(d_spec);
     if (d_stage_in_) (void)hipFree(d_stage_in_);
@@ -98,6 +100,7 @@ int Receiver::set_mixer(uint32_t ch, double f)
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     std::lock_guard<std::mutex> g(mu_);
     osc_.retune(ch, f);
+    sm_dirty_ = true;
     return 0;
 }
 
@@ -112,6 +115,21 @@ int Receiver::set_mode(uint32_t ch, int mode)
     std::lock_guard<std::mutex> g(mu_);
     if (ctl_[ch].mode != mode) am_list_dirty_ = true;
     ctl_[ch].mode = mode;
+    return 0;
+}
+
+int Receiver::enable_smeter(bool on)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (on && !bins) return fail(PEBBLEGPU_E_INVALID, "signal strength is measured on the spectrum: create the bank with spectrum_bins");
+    PG_HIP(hipSetDevice(device));
+    if (on && !d_smeter) {
+        smeter_pitch = (long long)max_sf * (long long)(superframe / nf);
+        PG_HIP(hipMalloc((void **)&d_smeter, sizeof(float4) * (size_t)smeter_pitch * C));
+        PG_HIP(hipMalloc((void **)&d_sm_bins, sizeof(SmBins) * C));
+        sm_dirty_ = true;
+    }
+    smeter_on = on;
     return 0;
 }
 
@@ -137,6 +155,7 @@ int Receiver::set_bandpass(uint32_t ch, double lo, double hi)
     if (c.bp_valid && flo == c.lo && fhi == c.hi) return 0;  // "return if no changes", fastfir.cpp:195-199
     c.lo = flo;  // stored before the sanity check, fastfir.cpp:200-203
     c.hi = fhi;
+    sm_dirty_ = true;
     c.bp_valid = true;
     const double rate = (double)demod_rate_int;
     if (flo >= fhi || flo >= rate / 2.0 || flo <= -rate / 2.0 || fhi >= rate / 2.0 || fhi <= -rate / 2.0)
@@ -148,6 +167,27 @@ int Receiver::set_bandpass(uint32_t ch, double lo, double hi)
 int Receiver::apply_controls()
 {
     if (int rc = osc_.upload(stream_)) return rc;
+    if (smeter_on && sm_dirty_) {
+        // bin indices of fdEstimate (signalstrength.cpp:313-337): integer bin width, truncating conversions, qBound
+        std::vector<SmBins> hb(C);
+        const int nb = (int)bins;
+        const double bin_width = (double)((uint32_t)fs / (uint32_t)nb);
+        auto qb = [nb](int v) { return v < 0 ? 0 : (v > nb ? nb : v); };
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const float lo = wfm ? -100000.f : (float)ctl_[ch].lo, hi = wfm ? 100000.f : (float)ctl_[ch].hi;  // receiver.cpp:891-892,959-960
+            const int mixer_bin = qb((int)(nb / 2 + (osc_.ctl[ch].freq / bin_width)));
+            SmBins &b = hb[ch];
+            b.lo = qb((int)(mixer_bin + (lo / bin_width)));
+            b.hi = qb((int)(mixer_bin + (hi / bin_width)));
+            b.bp_bins = b.hi - b.lo;
+            b.nlo = qb(b.lo - b.bp_bins);
+            b.nhi = qb(b.hi + b.bp_bins);
+            b.stream = shared_input ? 0 : (int)ch;
+        }
+        PG_HIP(hipMemcpyAsync(d_sm_bins, hb.data(), sizeof(SmBins) * C, hipMemcpyHostToDevice, stream_));
+        PG_HIP(hipStreamSynchronize(stream_));
+        sm_dirty_ = false;
+    }
     if (wfm) return 0;
     for (uint32_t ch = 0; ch < C; ch++) {
         ChanCtl &c = ctl_[ch];
@@ -197,6 +237,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
         if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
         last_spec_frames = n / nf;
+        if (smeter_on) {
+            const long long F = (long long)(n / nf);
+            if (int rc = run_signal_strength(stream_, d_spec, F * (long long)bins, (int)bins, F, d_sm_bins, d_smeter, smeter_pitch, C)) return rc;
+        }
     }
     PG_HIP(hipEventRecord(ev[1], stream_));
     tm.detailed[(tm.calls - 1) % Timers::kRing] = profile_detail;

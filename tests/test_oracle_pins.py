@@ -302,3 +302,15 @@ def test_agc_off_is_a_gain_and_on_settles_at_the_knee_curve(oracle_mod):
     ph = np.angle(tail * np.conj(x[-2000 - d:-d]))
     assert np.abs(ph).max() < 1e-9
 
+
+def test_fd_estimate_window_arithmetic(oracle_mod):
+    """fdEstimate on a synthetic dB spectrum: a flat -100 dB floor with a 7-bin -30 dB plateau centred on the mixer bin.
+    bin width 2048000/4096 = 500 Hz; band -4..4 kHz -> bins mixer-8 .. mixer+8 (17 bins inclusive, divided by bpBins = 16
+    as the reference does); peak -30, average 10*log10((7e-3 + 10e-10)/16), floor -100, snr 70."""
+    sp = np.full(4096, -100.0)
+    mixer_bin = 2048 + 200
+    sp[mixer_bin - 3:mixer_bin + 4] = -30.0
+    peak, avg, snr, floor = oracle_mod.fd_estimate(sp, 2048000, -4000, 4000, 100000.0)
+    assert peak == -30.0 and floor == -100.0 and abs(snr - 70.0) < 1e-9
+    assert abs(avg - 10 * np.log10((7 * 1e-3 + 10 * 1e-10) / 16)) < 1e-9
+

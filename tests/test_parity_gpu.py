@@ -663,6 +663,45 @@ def test_audio_tail_call_split_invariance_and_host_frames(gpu_lib, oracle_mod):
     assert rel_rms(np.concatenate(got), np.concatenate(want)) <= TOL
 
 
+def test_signal_strength_per_frame(gpu_lib, oracle_mod):
+    """S-meter (SignalStrength::fdEstimate) for two USB channels over a shared stream and for a WFM bank: (a) against the
+    oracle's fdEstimate applied to the oracle's OWN spectrum of each frame (end to end: <= 0.1 dB, from frame 1 on);
+    (b) against fdEstimate applied to the device spectrum (the reduction alone: ~1e-5 dB)."""
+    import pebblesdr_amd as P
+    fs, n, C, bins = 2048000, 2048, 2, 4096
+    fcs = [100e3, -300e3]
+    rx = P.ReceiverBank(fs, C, True, False, bins, max_superframes=1)
+    for c in range(C):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+    rx.enable_signal_strength(True)
+    sf = rx.superframe
+    x = tones(fs, sf, [(0.05, fcs[0] + 1000.0), (0.01, fcs[1] + 2000.0)]) + lcg_noise(sf, 3, 1e-3)
+    _, sp = rx.process(x)
+    sm = rx.signal_strength()
+    assert sm.shape == (C, sf // n, 4)
+    ref = oracle_mod.Receiver(fs, n, bins)
+    for f in range(sf // n):
+        _, rs = ref.process(x[f * n:(f + 1) * n])
+        for c in range(C):
+            own = oracle_mod.fd_estimate(sp[0, f].astype(np.float64), fs, np.float32(300), np.float32(3000), fcs[c])
+            assert np.abs(sm[c, f] - own).max() <= 1e-4
+            if f:
+                assert np.abs(sm[c, f] - oracle_mod.fd_estimate(rs, fs, np.float32(300), np.float32(3000), fcs[c])).max() <= TOL_DB
+    w = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=1)
+    w.set_mixer(0, 200e3)
+    w.enable_signal_strength(True)
+    t = np.arange(w.superframe) / fs
+    xw = 0.5 * np.exp(1j * (2 * np.pi * 200e3 * t + 75.0 * np.sin(2 * np.pi * 1000 * t))) + lcg_noise(w.superframe, 2, 1e-3)
+    _, spw = w.process(xw)
+    smw = w.signal_strength()
+    for f in (1, 7, w.superframe // n - 1):
+        own = oracle_mod.fd_estimate(spw[0, f].astype(np.float64), fs, np.float32(-100000), np.float32(100000), 200e3)
+        assert np.abs(smw[0, f] - own).max() <= 1e-4
+    plain = P.ReceiverBank(fs, 1, True, False, 0)
+    with pytest.raises(P.PebbleGpuError):
+        plain.enable_signal_strength(True)  # no spectrum to measure on
+
+
 def test_error_paths(gpu_lib):
     import pebblesdr_amd as P
     rx = P.ReceiverBank(2048000, 2, True, False, 0)
