@@ -342,9 +342,13 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
     if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-    launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), C), dim3(256), mixdec_lds_bytes(first), s, d_in, in_pitch, (int)shared_input, buf0.data(),
+    // merged CIC3 over a shared stream: one workgroup mixes a group of channels from one fetch of the sample pairs
+    const int cg = (first.cic3 && first.stride > 2 && shared_input) ? 8 : 1;
+    size_t lds = mixdec_lds_bytes(first);
+    if (cg > 1 && lds < (size_t)cg * 258 * sizeof(float4)) lds = (size_t)cg * 258 * sizeof(float4);
+    launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), cdiv(C, cg)), dim3(256), lds, s, d_in, in_pitch, (int)shared_input, buf0.data(),
                buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], (int)kMaxTaps, (const float *)osc.d_amp,
-               osc.a_inf, first, d_hist_mixed[hist_parity ^ 1], osc.inline_dyn);  // its last block leaves the next call's mixed history
+               osc.a_inf, first, d_hist_mixed[hist_parity ^ 1], osc.inline_dyn, cg, (int)C);  // its last block leaves the next call's mixed history
     hist_parity ^= 1;
     if (after_first) PG_HIP(hipEventRecord(after_first, s));
     len_out = len0;

@@ -58,7 +58,8 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
                                                           float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                           const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
                                                           int hist_pitch, const float *__restrict__ amp_tab, float a_inf,
-                                                          FirTaps taps, float2 *__restrict__ hist_out, OscDynInline dyn)
+                                                          FirTaps taps, float2 *__restrict__ hist_out, OscDynInline dyn, int chan_group,
+                                                          int n_chan)
 {
     HIP_DYNAMIC_SHARED(float2, tile)
     __shared__ float ht[kMaxTaps];  // taps out of the kernel-argument segment: the tap loop must not wait on scalar loads
@@ -78,6 +79,63 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
     const uint32_t n0 = dyn.use ? dyn.d[c].n0 : oc->n0;
     const bool mix = (dyn.use ? dyn.d[c].mix_on : oc->mix_on) != 0;
     const bool settled = n0 >= (uint32_t)kAmpTab; // amplitude transient over: a_n == sqrt(0.95) to fp32
+    if (taps.cic3 && S > 2) {
+        // Merged CIC3 at stride S reads only the pair m[oS], m[oS+1] of every S inputs (decimator.cpp:719-737 as merged):
+        // fetch and mix just those pairs -- pair p of this tile is input (o0 + p - 1)*S, p = 0 .. nout.  With a shared
+        // input one workgroup serves chan_group channels from ONE fetch of the pairs (each pair is 16 bytes of a 128-byte
+        // line: per-channel fetches would pull the whole stream through L2 once per channel).
+        float4 *pairs = reinterpret_cast<float4 *>(tile);
+        const int c0 = blockIdx.y * chan_group;
+        const int ng = (n_chan - c0) < chan_group ? (n_chan - c0) : chan_group;
+        for (int p = t; p <= nout; p += 256) {
+            const long long i = (o0 + p - 1) * (long long)S;
+            float4 xx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i >= 0 && shared_input) xx = *reinterpret_cast<const float4 *>(in + i);
+            for (int g = 0; g < ng; g++) {
+                const int cg = c0 + g;
+                const ChanOsc *og = &osc[cg];
+                float2 a, b;
+                if (i < 0) {
+                    a = hist[(long long)cg * hist_pitch];
+                    b = hist[(long long)cg * hist_pitch + 1];
+                } else {
+                    if (!shared_input) xx = *reinterpret_cast<const float4 *>(in + (long long)cg * in_pitch + i);
+                    a = make_float2(xx.x, xx.y);
+                    b = make_float2(xx.z, xx.w);
+                    const bool gmix = (dyn.use ? dyn.d[cg].mix_on : og->mix_on) != 0;
+                    if (gmix) {
+                        const double gph0 = dyn.use ? dyn.d[cg].phase0 : og->phase0;
+                        const uint32_t gn0 = dyn.use ? dyn.d[cg].n0 : og->n0;
+                        const bool gset = gn0 >= (uint32_t)kAmpTab;
+                        const float2 ph = cis_cycles(gph0 + (double)(i + 1) * og->inc);
+                        const float2 ph1 = cmul(ph, og->step[1]);
+                        const float aa = gset ? a_inf : osc_amp(amp_tab, a_inf, gn0, i);
+                        const float ab = gset ? a_inf : osc_amp(amp_tab, a_inf, gn0, i + 1);
+                        a = cmul(cscale(ph, aa), a);
+                        b = cmul(cscale(ph1, ab), b);
+                    }
+                }
+                pairs[g * 258 + p] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        __syncthreads();
+        for (int g = 0; g < ng; g++) {
+            const int cg = c0 + g;
+            const float4 *pg = pairs + g * 258;
+            if (hist_out != nullptr && o0 + nout == n_out && t < 2) {
+                const float4 last = pg[nout];  // m[n-S], m[n-S+1]: the next call's previous pair
+                hist_out[(long long)cg * hist_pitch + t] = t == 0 ? make_float2(last.x, last.y) : make_float2(last.z, last.w);
+            }
+            if (t < nout) {
+                const float4 pv = pg[t], cu = pg[t + 1];
+                float2 acc;
+                acc.x = .125f * (cu.z + pv.x + 3.0f * (pv.z + cu.x));
+                acc.y = .125f * (cu.w + pv.y + 3.0f * (pv.w + cu.y));
+                out[(long long)cg * out_pitch + o0 + t] = cscale(acc, taps.gain);
+            }
+        }
+        return;
+    }
     float2 ph = make_float2(1.f, 0.f);
     int sweep = 0;
     // Loads are issued kLoadBatch at a time before any of them is consumed: with one 16-byte load in flight per
