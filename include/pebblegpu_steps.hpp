@@ -232,8 +232,9 @@ private:
 // processIQData's DSP for one tuned channel, audio delivered through the CB_ProcessAudioData-shaped callback.
 class Receiver {
 public:
+    // audioOutRate: Key_AudioOutputSampleRate (receiver.cpp:203); 0 keeps the audio at the demod rate
     Receiver(uint32_t sampleRate, uint16_t framesPerBuffer, bool wfm, uint32_t spectrumBins, CB_ProcessAudioData audioCb,
-             uint32_t fastfirFft = 0, uint32_t fastfirTaps = 0, int device = 0)
+             uint32_t fastfirFft = 0, uint32_t fastfirTaps = 0, int device = 0, uint32_t audioOutRate = 0)
         : n(framesPerBuffer), cb(audioCb)
     {
         pebblegpu_config cfg;
@@ -249,6 +250,7 @@ public:
         cfg.fastfir_fft = fastfirFft;
         cfg.fastfir_taps = fastfirTaps;
         cfg.max_superframes = 1;
+        cfg.audio_rate = audioOutRate;
         status = report("receiver_create", pebblegpu_receiver_create(&cfg, &h));
         pebblegpu_info info;
         if (h && pebblegpu_receiver_info(h, &info) == 0) {
@@ -263,6 +265,8 @@ public:
     void mixerChanged(int f) { if (h) status = report("set_mixer_freq", pebblegpu_set_mixer_freq(h, 0, f)); }               // receiver.cpp:709
     void filterChanged(int lo, int hi) { if (h) status = report("set_bandpass", pebblegpu_set_bandpass(h, 0, lo, hi)); }    // receiver.cpp:658
     void demodModeChanged(DemodMode m) { if (h) status = report("set_demod_mode", pebblegpu_set_demod_mode(h, 0, (int)m)); } // receiver.cpp:640
+    // agcModeChanged / agcThresholdChanged -> AGC::setAgcMode(mode, threshold) (agc.cpp:53-82)
+    void agcModeChanged(int agcMode, int threshold) { if (h) status = report("set_agc", pebblegpu_set_agc(h, 0, agcMode, threshold)); }
     // bound as the device plugin's CB_ProcessIQData, like receiver.cpp:135-138
     void processIQData(CPX *in, uint16_t numSamples)
     {
