@@ -761,3 +761,82 @@ def test_full_size_properties_config2(gpu_lib):
     assert np.all(np.argmax(SA[0][1:], axis=1) == 4096 + 4 * 205)
     # unmodulated carrier at DC after mixing: discriminator output 0 (after the start-up transient)
     assert np.abs(A[0][4096:]).max() < 1e-4
+
+
+def test_full_size_configs2_256_ssb_channels(gpu_lib, oracle_mod):
+    """BASELINE configs[2] at size: one 2.048 Msps stream, 256 tuned USB channels (f_c = -960 kHz + 7.5 kHz c), a tone
+    1000 + 3.1 c Hz above every carrier, two super-frames in one call.  Oracle on three channels; for all 256: the tone
+    comes out at its own offset with the level the chain predicts (0.003 x the 10^(2*5/20) gain restore)."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 256
+    fcs = [-960e3 + 7.5e3 * c for c in range(C)]
+    rng = np.random.RandomState(3)
+    ph = rng.uniform(0, 2 * np.pi, C)
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    for c, fc in enumerate(fcs):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fc); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    x = tones(fs, 2 * sf, [(0.003, fcs[c] + 1000.0 + 3.1 * c, ph[c]) for c in range(C)]) + lcg_noise(2 * sf, 3, 1e-4)
+    g = rx.process(x)[0]
+    assert g.shape == (C, 2 * sf // rx.D)
+    rate = fs / rx.D
+    w = np.hanning(2048)
+    for c in range(C):
+        sp = np.abs(np.fft.fft(g[c][2048:] * w))
+        k = int(np.argmax(sp))
+        f = k * rate / 2048
+        assert abs(f - (1000.0 + 3.1 * c)) <= rate / 2048  # within a bin
+        amp = sp[k - 2:k + 3].max() / (w.sum())
+        assert abs(amp / (0.003 * 10 ** (2 * 5 / 20.0)) - 1.0) < 0.2  # scalloping of a Hann bin: within 20 %
+    for c in (0, 100, 255):
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fcs[c]); r.set_filter(300, 3000)
+        want = np.concatenate([r.process(x[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(2 * sf // n)])
+        assert rel_rms(g[c], want) <= TOL
+
+
+def test_full_size_configs3_512_channel_shard(gpu_lib, oracle_mod):
+    """BASELINE configs[3], one GPU's shard at size: a 100 Msps stream, 512 AM/USB channels, one super-frame (4.2 M input
+    samples, D = 2048).  Sixteen channels carry a signal; oracle (mixer + decimator + band-pass [+ AM]) on three of them,
+    and every signalled channel shows its modulation at the right place."""
+    import pebblesdr_amd as P
+    fs, C = 100_000_000, 512
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    assert rx.D == 2048
+    sf = rx.superframe
+    rate = int(rx.info.demod_rate_int)
+    fcs = [-44.8e6 + 175e3 * c for c in range(C)]
+    lit = list(range(5, C, 32))  # 16 channels
+    t = np.arange(sf) / fs
+    x = lcg_noise(sf, 4, 1e-3)
+    for c in lit:
+        if c % 2 == 0:
+            x = x + 0.05 * (1 + 0.5 * np.cos(2 * np.pi * 800 * t)) * np.exp(2j * np.pi * fcs[c] * t)
+        else:
+            x = x + 0.05 * np.exp(2j * np.pi * (fcs[c] + 1200.0) * t)
+    for c in range(C):
+        rx.set_mixer(c, fcs[c])
+        if c % 2 == 0:
+            rx.set_mode(c, P.DM_AM); rx.set_bandpass(c, -5000, 5000)
+        else:
+            rx.set_mode(c, P.DM_USB); rx.set_bandpass(c, 300, 3000)
+    g = rx.process(x)[0]
+    assert g.shape == (C, 2048)
+    w = np.hanning(1024)
+    for c in lit:
+        sp = np.abs(np.fft.fft(g[c][1024:] * w))
+        k = int(np.argmax(sp[1:512])) + 1
+        assert abs(k * rate / 1024 - (800.0 if c % 2 == 0 else 1200.0)) <= rate / 1024
+    for c in (lit[0], lit[7], lit[15]):
+        mix = oracle_mod.Mixer(fs); mix.set_frequency(fcs[c])
+        dec = oracle_mod.Decimator(fs, 30000)
+        z = dec.process(mix.process(x)) * 10 ** (2 * 11 / 20.0)
+        ff = oracle_mod.FastFIR()
+        if c % 2 == 0:
+            ff.setup(-5000, 5000, 0, rate)
+            want = oracle_mod.DemodAM(rate, 10000).process(ff.process(z))
+        else:
+            ff.setup(300, 3000, 0, rate)
+            want = ff.process(z)
+        assert rel_rms(g[c], want) <= TOL
+
