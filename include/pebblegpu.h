@@ -161,6 +161,17 @@ int pebblegpu_receiver_set_profiling(pebblegpu_receiver *rx, int per_kernel);
 /* the same, averaged over the last `last_k` process calls (the library keeps events for 64): lets a caller queue calls
  * back to back without a host sync per call and read the kernel times afterwards */
 int pebblegpu_receiver_mean_ms(const pebblegpu_receiver *rx, int which, uint32_t last_k, float *ms);
+/* Input conditioners, applied in the reference's order to a copy of the stream before the spectrum and the mixer
+ * (receiver.cpp:814-823); all default-off.  flags: PEBBLEGPU_COND_* or'ed.  DC: DCRemoval (CIir high-pass 10 Hz, Q
+ * 0.7071, dcremoval.cpp:3-19); IQBALANCE: IQBalance::ProcessBlock with setGainFactor/setPhaseFactor values
+ * (iqbalance.cpp:65-86); NB1/NB2: NoiseBlanker::ProcessBlock/ProcessBlock2 (noiseblanker.cpp:45-97; switching one on
+ * resets its averages as setNbEnabled does).  These are serial-in-time algorithms: the library runs one lane per stream
+ * (per frame for IQBALANCE), so they parallelise over banks of streams, not within one.  Batched device path only. */
+enum { PEBBLEGPU_COND_DC = 1, PEBBLEGPU_COND_IQBALANCE = 2, PEBBLEGPU_COND_NB1 = 4, PEBBLEGPU_COND_NB2 = 8 };
+int pebblegpu_set_conditioners(pebblegpu_receiver *rx, uint32_t stream, int flags, double iq_gain, double iq_phase);
+/* NoiseFilter (ANF, 45-tap leaky LMS on a 64-sample delay, noisefilter.cpp:31-88) on a narrow channel, between the
+ * band-pass and the AGC (receiver.cpp:974) */
+int pebblegpu_set_noise_filter(pebblegpu_receiver *rx, uint32_t channel, int on);
 /* S-meter: SignalStrength::fdEstimate (application/signalstrength.cpp:287-380; receiver.cpp:891-892, 959-960) on every
  * frame's unprocessed spectrum, per channel: float4 (peakDb, avgDb, snrDb, floorDb) at [channel * pitch + frame].  The
  * band window is the channel's band-pass (+-100 kHz in a WFM bank) around its mixer frequency.  avgDb is the value the

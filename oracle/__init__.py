@@ -73,6 +73,15 @@ def lib():
         L.po_receiver_process.restype = C.c_uint32
         L.po_receiver_process.argtypes = [C.c_void_p, _dp, C.c_uint32, _dp, _dp]
         L.po_receiver_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.po_receiver_set_conditioners.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.po_receiver_set_anf.argtypes = [C.c_void_p, C.c_int]
+        L.po_iq_balance.argtypes = [C.c_double, C.c_double, _dp, _dp, C.c_int]
+        L.po_anf_init.argtypes = [C.c_void_p]
+        L.po_anf_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.po_nb_init.argtypes = [C.c_void_p]
+        L.po_nb_enable.argtypes = [C.c_void_p, C.c_int]
+        L.po_nb1_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.po_nb2_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.po_receiver_set_audio_rate.argtypes = [C.c_void_p, C.c_uint32]
         L.po_fd_estimate.restype = C.c_double
         L.po_fd_estimate.argtypes = [_dp, C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_double, _dp]
@@ -397,6 +406,54 @@ def fd_estimate(spectrum_db, spectrum_rate, bp_lo, bp_hi, mixer_freq):
     return out
 
 
+class _AnfS(C.Structure):
+    _fields_ = [("coeff", C.c_double * 90), ("delay", C.c_double * 1024), ("head", C.c_int), ("last", C.c_int)]
+
+
+class Anf:
+    """NoiseFilter::ProcessBlock (ANF), application/noisefilter.cpp"""
+
+    def __init__(self):
+        self.s = _AnfS()
+        lib().po_anf_init(C.byref(self.s))
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty_like(x)
+        lib().po_anf_process(C.byref(self.s), _ptr(x), _ptr(out), len(x))
+        return out
+
+
+class _NbS(C.Structure):
+    _fields_ = [("nb_avg_mag", C.c_float), ("nb2_avg_mag", C.c_float), ("spike_count", C.c_int), ("nb2_avg", C.c_double * 2),
+                ("delay", C.c_double * 16), ("head", C.c_int), ("last", C.c_int)]
+
+
+class NoiseBlanker:
+    """NoiseBlanker::ProcessBlock / ProcessBlock2, application/noiseblanker.cpp"""
+
+    def __init__(self):
+        self.s = _NbS()
+        lib().po_nb_init(C.byref(self.s))
+
+    def enable(self, which):
+        lib().po_nb_enable(C.byref(self.s), int(which))
+
+    def process(self, x, which=1):
+        x = _c128(x)
+        out = np.empty_like(x)
+        (lib().po_nb1_process if which == 1 else lib().po_nb2_process)(C.byref(self.s), _ptr(x), _ptr(out), len(x))
+        return out
+
+
+def iq_balance(x, gain, phase):
+    """IQBalance::ProcessBlock on one block"""
+    x = _c128(x)
+    out = np.empty_like(x)
+    lib().po_iq_balance(float(gain), float(phase), _ptr(x), _ptr(out), len(x))
+    return out
+
+
 class Agc:
     """application/agc.cpp"""
 
@@ -472,6 +529,12 @@ class Receiver:
 
     def set_agc(self, mode, threshold):
         lib().po_receiver_set_agc(self.h, int(mode), int(threshold))
+
+    def set_conditioners(self, flags, iq_gain=1.0, iq_phase=0.0):
+        lib().po_receiver_set_conditioners(self.h, int(flags), float(iq_gain), float(iq_phase))
+
+    def set_anf(self, on=True):
+        lib().po_receiver_set_anf(self.h, 1 if on else 0)
 
     def set_audio_rate(self, rate):
         lib().po_receiver_set_audio_rate(self.h, int(rate))

@@ -901,6 +901,102 @@ int po_resampler_process(po_resampler *r, int n, double rate, const double *in, 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * IQBalance, NoiseBlanker, NoiseFilter -- application/{iqbalance,noiseblanker,noisefilter}.cpp
+ * ---------------------------------------------------------------------------------------------- */
+void po_iq_balance(double gain_factor, double phase_factor, const double *in, double *out, int n)
+{
+    double t1r = 0, t1i = 0, t2r = 0, t2i = 0;
+    const float mu = 0.0025f;
+    for (int i = 0; i < n; i++) {
+        const double orr = in[2 * i] * gain_factor;
+        const double oi = in[2 * i + 1] + (in[2 * i] * phase_factor);
+        /* t1 = out + t2 * conj(out) */
+        t1r = orr + (t2r * orr + t2i * oi);
+        t1i = oi + (t2i * orr - t2r * oi);
+        /* t2 = t2 * (1 - mu*1e-6) - (t1*t1) * mu */
+        const double sc = 1.0 - mu * 0.000001;
+        const double sqr = t1r * t1r - t1i * t1i, sqi = 2.0 * t1r * t1i;
+        t2r = t2r * sc - sqr * mu;
+        t2i = t2i * sc - sqi * mu;
+        out[2 * i] = t1r;
+        out[2 * i + 1] = t1i;
+    }
+}
+
+void po_nb_init(po_nb *b)
+{
+    memset(b, 0, sizeof(*b));
+    b->nb_avg_mag = 1; b->nb2_avg_mag = 1; b->spike_count = 0; /* noiseblanker.cpp:9-15 */
+}
+void po_nb_enable(po_nb *b, int which)
+{
+    if (which == 1) { b->spike_count = 0; b->nb_avg_mag = 0; }
+    else { b->nb2_avg_mag = 0; b->nb2_avg[0] = b->nb2_avg[1] = 0; }
+}
+void po_nb1_process(po_nb *b, const double *in, double *out, int n)
+{
+    const int size = 8, delay = 2, spike = 7;
+    const double threshold = 3.3;
+    for (int i = 0; i < n; i++) {
+        const float mag = (float)sqrt(in[2 * i] * in[2 * i] + in[2 * i + 1] * in[2 * i + 1]);
+        b->delay[2 * b->head] = in[2 * i]; b->delay[2 * b->head + 1] = in[2 * i + 1]; /* DelayLine::NewSample */
+        b->last = b->head;
+        b->head = b->head == 0 ? size - 1 : b->head - 1;
+        b->nb_avg_mag = (float)((0.999 * b->nb_avg_mag) + (0.001 * mag));
+        if (b->spike_count == 0 && mag > (b->nb_avg_mag * threshold)) b->spike_count = spike;
+        if (b->spike_count > 0) {
+            out[2 * i] = 0.0; out[2 * i + 1] = 0.0;
+            b->spike_count--;
+        } else {
+            const int nx = (b->last + delay + 0) % size; /* NextDelay(0) */
+            out[2 * i] = b->delay[2 * nx]; out[2 * i + 1] = b->delay[2 * nx + 1];
+        }
+    }
+}
+void po_nb2_process(po_nb *b, const double *in, double *out, int n)
+{
+    const double threshold = 3.3;
+    for (int i = 0; i < n; i++) {
+        const float mag = (float)sqrt(in[2 * i] * in[2 * i] + in[2 * i + 1] * in[2 * i + 1]);
+        b->nb2_avg[0] = b->nb2_avg[0] * 0.75 + in[2 * i] * 0.25;
+        b->nb2_avg[1] = b->nb2_avg[1] * 0.75 + in[2 * i + 1] * 0.25;
+        b->nb2_avg_mag = (float)(0.999 * b->nb2_avg_mag + 0.001 * mag);
+        if (mag > (threshold * b->nb2_avg_mag)) { out[2 * i] = b->nb2_avg[0]; out[2 * i + 1] = b->nb2_avg[1]; }
+        else { out[2 * i] = in[2 * i]; out[2 * i + 1] = in[2 * i + 1]; }
+    }
+}
+
+void po_anf_init(po_anf *a) { memset(a, 0, sizeof(*a)); }
+void po_anf_process(po_anf *a, const double *in, double *out, int n)
+{
+    const int size = 512, delay = 64, taps = 45;
+    const double rate = 0.01, leakage = 0.00001;
+    const double scl1 = 1.0 - rate * leakage;
+    for (int i = 0; i < n; i++) {
+        const double inr = in[2 * i], ini = in[2 * i + 1]; /* the reference's in and out are distinct buffers */
+        a->delay[2 * a->head] = inr; a->delay[2 * a->head + 1] = ini;
+        a->last = a->head;
+        a->head = a->head == 0 ? size - 1 : a->head - 1;
+        double sosr = 0, sosi = 0, accr = 0, acci = 0;
+        for (int j = 0; j < taps; j++) {
+            const int nx = (a->last + delay + j) % size;
+            const double dr = a->delay[2 * nx], di = a->delay[2 * nx + 1];
+            sosr = sosr + (dr * dr); sosi = sosi + (di * di);
+            accr = accr + a->coeff[2 * j] * dr; acci = acci + a->coeff[2 * j + 1] * di;
+        }
+        out[2 * i] = accr * 1.25; out[2 * i + 1] = acci * 1.25;
+        double er = inr - accr, ei = ini - acci;
+        er = er * (rate / (sosr + 1e-10));
+        ei = ei * (rate / (sosi + 1e-10));
+        for (int j = 0; j < taps; j++) {
+            const int nx = (a->last + delay + j) % size;
+            a->coeff[2 * j] = a->coeff[2 * j] * scl1 + er * a->delay[2 * nx];
+            a->coeff[2 * j + 1] = a->coeff[2 * j + 1] * scl1 + ei * a->delay[2 * nx + 1];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * SignalStrength::fdEstimate -- application/signalstrength.cpp:287-380, pebblelib/db.h
  * ---------------------------------------------------------------------------------------------- */
 static int po_qbound(int lo, int v, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -956,6 +1052,8 @@ struct po_receiver {
     po_demod_wfm wfm;
     double *mixed, *working, *samplebuf, *bpout, *demodout;
     uint32_t samplebuf_len;
+    int cond_flags; double iq_gain, iq_phase; po_iir dc; po_nb nb; po_anf anf; int anf_on;
+    double *cond;            /* conditioned input frame */
     po_agc *agc;             /* receiver.cpp:264 AGC(m_demodSampleRate, m_demodFrames) */
     po_resampler *resamp;    /* receiver.cpp:184 */
     uint32_t audio_rate;     /* 0: resampRate == 1 branch (copyCPX) */
@@ -981,6 +1079,11 @@ po_receiver *po_receiver_new(uint32_t fs, uint32_t n, uint32_t spectrum_bins, ui
     r->samplebuf = (double *)calloc((size_t)n * 2, sizeof(double));
     r->bpout = (double *)calloc((size_t)n * 2 + 2 * (size_t)(fastfir_fft ? fastfir_fft : 2048), sizeof(double));
     r->demodout = (double *)calloc((size_t)n * 2 + 2 * (size_t)(fastfir_fft ? fastfir_fft : 2048), sizeof(double));
+    r->cond = (double *)calloc((size_t)n * 2, sizeof(double));
+    po_iir_init_hp(&r->dc, 10, 0.7071, (double)fs); /* dcremoval.cpp:5-9 */
+    po_nb_init(&r->nb);
+    po_anf_init(&r->anf);
+    r->iq_gain = 1; r->iq_phase = 0;
     r->agc = po_agc_new((double)r->demod_rate);
     r->resamp = po_resampler_new((int)n + (int)(fastfir_fft ? fastfir_fft : 2048));
     r->audio_rate = 0;
@@ -993,7 +1096,7 @@ void po_receiver_free(po_receiver *r)
     po_decimator_free(r->dec); po_decimator_free(r->dec_wfm);
     po_spectrum_free(r->spec); po_fastfir_free(r->bp);
     free(r->mixed); free(r->working); free(r->samplebuf); free(r->bpout); free(r->demodout);
-    po_agc_free(r->agc); po_resampler_free(r->resamp);
+    po_agc_free(r->agc); po_resampler_free(r->resamp); free(r->cond);
     free(r);
 }
 
@@ -1013,6 +1116,15 @@ uint32_t po_receiver_dec_stages(const po_receiver *r, int wfm)
 
 uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, double *audio, double *spectrum_db)
 {
+    /* :814-823 DC removal, IQ balance, noise blankers -- each returns its own buffer when enabled */
+    if (r->cond_flags) {
+        memcpy(r->cond, in, sizeof(double) * 2 * (size_t)n);
+        if (r->cond_flags & 1) po_iir_process_cpx(&r->dc, (int)n, r->cond, r->cond);
+        if (r->cond_flags & 2) po_iq_balance(r->iq_gain, r->iq_phase, r->cond, r->cond, (int)n);
+        if (r->cond_flags & 4) po_nb1_process(&r->nb, r->cond, r->cond, (int)n);
+        if (r->cond_flags & 8) po_nb2_process(&r->nb, r->cond, r->cond, (int)n);
+        in = r->cond;
+    }
     /* :826 SignalSpectrum::unprocessed (timer gate forced open: every frame) */
     if (r->spec && spectrum_db) po_spectrum_process(r->spec, in, n, spectrum_db);
     const double *next = in;
@@ -1046,7 +1158,9 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     int nb = po_fastfir_process(r->bp, (int)ns, r->samplebuf, r->bpout);
     if (nb <= 0) return 0;
     if (r->mode == PO_NONE) { memset(audio, 0, (size_t)nb * 2 * sizeof(double)); return (uint32_t)nb; } /* :968-971 */
-    /* :983 AGC (ANF identity, see header), written back over the band-pass output buffer */
+    /* :974 NoiseFilter (ANF) */
+    if (r->anf_on) po_anf_process(&r->anf, r->bpout, r->bpout, nb);
+    /* :983 AGC, written back over the band-pass output buffer */
     po_agc_process(r->agc, r->bpout, r->bpout, nb);
     /* :987 demod */
     double *dst = r->audio_rate ? r->demodout : audio;
@@ -1059,5 +1173,12 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     return (uint32_t)po_resampler_process(r->resamp, nb, ((double)r->demod_rate * 1.0) / ((double)r->audio_rate * 1.0), r->demodout, audio);
 }
 
+void po_receiver_set_conditioners(po_receiver *r, int flags, double gain_factor, double phase_factor)
+{
+    if ((flags & 4) && !(r->cond_flags & 4)) po_nb_enable(&r->nb, 1);
+    if ((flags & 8) && !(r->cond_flags & 8)) po_nb_enable(&r->nb, 2);
+    r->cond_flags = flags; r->iq_gain = gain_factor; r->iq_phase = phase_factor;
+}
+void po_receiver_set_anf(po_receiver *r, int on) { r->anf_on = on; }
 void po_receiver_set_agc(po_receiver *r, int mode, int threshold) { po_agc_set_mode(r->agc, mode, threshold); }
 void po_receiver_set_audio_rate(po_receiver *r, uint32_t audio_rate) { r->audio_rate = audio_rate; }

@@ -158,6 +158,26 @@ void po_resampler_free(po_resampler *r);
 int po_resampler_process(po_resampler *r, int n, double rate, const double *in, double *out);
 double po_resampler_time(const po_resampler *r);              /* m_FloatTime, for tests */
 
+/* ------------------------------------------------------------------------------------------------
+ * Pre-chain conditioners and the noise filter (all default-off in the reference; parity unpinned: no
+ * recorded values).  DCRemoval is po_iir_init_hp(10, 0.7071, fs) + po_iir_process_cpx (dcremoval.cpp:3-19).
+ * ---------------------------------------------------------------------------------------------- */
+/* IQBalance::ProcessBlock, application/iqbalance.cpp:65-86 (t1, t2 restart at zero every block) */
+void po_iq_balance(double gain_factor, double phase_factor, const double *in, double *out, int n);
+/* NoiseBlanker::ProcessBlock / ProcessBlock2, application/noiseblanker.cpp:45-97 */
+typedef struct {
+    float nb_avg_mag, nb2_avg_mag; int spike_count; double nb2_avg[2];
+    double delay[16]; int head, last;   /* DelayLine(8, 2), pebblelib/delayline.cpp */
+} po_nb;
+void po_nb_init(po_nb *b);
+void po_nb_enable(po_nb *b, int which);  /* setNbEnabled(true) / setNb2Enabled(true) resets */
+void po_nb1_process(po_nb *b, const double *in, double *out, int n);
+void po_nb2_process(po_nb *b, const double *in, double *out, int n);
+/* NoiseFilter::ProcessBlock (ANF, LMS), application/noisefilter.cpp:31-88 */
+typedef struct { double coeff[2 * 45]; double delay[2 * 512]; int head, last; } po_anf;
+void po_anf_init(po_anf *a);
+void po_anf_process(po_anf *a, const double *in, double *out, int n);
+
 /* SignalStrength::fdEstimate (application/signalstrength.cpp:287-380) on one dB spectrum, update-timer gate forced
  * open.  out[4] = peakDb, avgDb, snrDb, floorDb.  Returns avgDb.  Integer bin width (quint32 / int) as written. */
 double po_fd_estimate(const double *spectrum, int bins, uint32_t spectrum_rate, float bp_lo, float bp_hi, double mixer_freq, double *out);
@@ -180,6 +200,10 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
  * audio_rate 0 leaves the audio at the demod rate (the resampRate == 1 branch) */
 void po_receiver_set_agc(po_receiver *r, int mode, int threshold);
 void po_receiver_set_audio_rate(po_receiver *r, uint32_t audio_rate);
+/* flags: 1 DCRemoval, 2 IQBalance (with gain/phase factors), 4 NoiseBlanker 1, 8 NoiseBlanker 2 (receiver.cpp:814-823,
+ * in that order, before the spectrum and the mixer); anf: NoiseFilter on the narrow branch (receiver.cpp:974) */
+void po_receiver_set_conditioners(po_receiver *r, int flags, double gain_factor, double phase_factor);
+void po_receiver_set_anf(po_receiver *r, int on);
 
 #ifdef __cplusplus
 }

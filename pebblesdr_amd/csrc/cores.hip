@@ -829,6 +829,144 @@ int AgcCore::run(hipStream_t s, float2 *buf, long long pitch, long long n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// ConditionCore, AnfCore
+// ------------------------------------------------------------------------------------------------
+int ConditionCore::init(uint32_t streams, uint32_t frame, double sample_rate, long long max_n)
+{
+    S = streams;
+    nf = frame;
+    fs = sample_rate;
+    cap = max_n;
+    host.assign(S, Host());
+    const design::Biquad h = design::biquad_highpass(10, 0.7071, fs);  // DCRemoval ctor, dcremoval.cpp:5-9
+    const double c[5] = {h.b0, h.b1, h.b2, h.a1, h.a2};
+    fill_scan_section(dc.sec[0], kBiquadDf2, c);
+    return 0;
+}
+void ConditionCore::release()
+{
+    void *p[] = {d_buf, d_dc_state, d_dc_list, d_iq, d_nb};
+    for (void *q : p) if (q) (void)hipFree(q);
+    d_buf = nullptr; d_dc_state = nullptr; d_dc_list = nullptr; d_iq = nullptr; d_nb = nullptr;
+}
+int ConditionCore::set(uint32_t stream, int flags, double gain, double phase)
+{
+    if (stream >= S || flags < 0 || flags > 15) return fail(PEBBLEGPU_E_INVALID, "bad stream or conditioner flags");
+    Host &h = host[stream];
+    if (!d_buf) {  // first use: the conditioned copy and the per-stream state
+        PG_HIP(hipMalloc((void **)&d_buf, sizeof(float2) * (size_t)cap * S));
+        PG_HIP(hipMalloc((void **)&d_dc_state, sizeof(double) * 4 * S));
+        PG_HIP(hipMemset(d_dc_state, 0, sizeof(double) * 4 * S));
+        PG_HIP(hipMalloc((void **)&d_dc_list, sizeof(int) * S));
+        PG_HIP(hipMalloc((void **)&d_iq, sizeof(double2) * S));
+        PG_HIP(hipMalloc((void **)&d_nb, sizeof(NbState) * S));
+        std::vector<NbState> nb(S);
+        memset(nb.data(), 0, sizeof(NbState) * S);
+        for (auto &b : nb) { b.nb_avg_mag = 1; b.nb2_avg_mag = 1; }  // NoiseBlanker ctor, noiseblanker.cpp:9-15
+        PG_HIP(hipMemcpy(d_nb, nb.data(), sizeof(NbState) * S, hipMemcpyHostToDevice));
+    }
+    // setNbEnabled(true) / setNb2Enabled(true) reset their averages (noiseblanker.cpp:20-37)
+    const int turned_on = flags & ~h.flags;
+    if (turned_on & 12) {
+        NbState b;
+        PG_HIP(hipDeviceSynchronize());
+        PG_HIP(hipMemcpy(&b, d_nb + stream, sizeof(b), hipMemcpyDeviceToHost));
+        if (turned_on & 4) { b.spike_count = 0; b.nb_avg_mag = 0; }
+        if (turned_on & 8) { b.nb2_avg_mag = 0; b.nb2_avg[0] = b.nb2_avg[1] = 0; }
+        PG_HIP(hipMemcpy(d_nb + stream, &b, sizeof(b), hipMemcpyHostToDevice));
+    }
+    h.flags = flags;
+    h.gain = gain;
+    h.phase = phase;
+    dirty = true;
+    return 0;
+}
+int ConditionCore::apply(hipStream_t s)
+{
+    if (!dirty) return 0;
+    PG_HIP(hipStreamSynchronize(s));
+    any = iq_any = nb_any = false;
+    dc_list.clear();
+    std::vector<double2> iq(S);
+    for (uint32_t i = 0; i < S; i++) {
+        const Host &h = host[i];
+        if (h.flags) any = true;
+        if (h.flags & 1) dc_list.push_back((int)i);
+        iq[i] = (h.flags & 2) ? make_double2(h.gain, h.phase) : make_double2(-1.0, 0.0);
+        if (h.flags & 2) iq_any = true;
+        if (h.flags & 12) nb_any = true;
+        const int nbf = (h.flags >> 2) & 3;
+        PG_HIP(hipMemcpy(&d_nb[i].flags, &nbf, sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (!dc_list.empty()) PG_HIP(hipMemcpy(d_dc_list, dc_list.data(), sizeof(int) * dc_list.size(), hipMemcpyHostToDevice));
+    PG_HIP(hipMemcpy(d_iq, iq.data(), sizeof(double2) * S, hipMemcpyHostToDevice));
+    dirty = false;
+    return 0;
+}
+int ConditionCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n, const float2 **out, long long *out_pitch)
+{
+    *out = d_in;
+    *out_pitch = in_pitch;
+    if (!any) return 0;
+    if (n > cap || n % nf != 0) return fail(PEBBLEGPU_E_SIZE, "conditioners take whole frames within the bank's capacity");
+    PG_HIP(hipMemcpy2DAsync(d_buf, sizeof(float2) * (size_t)cap, d_in, sizeof(float2) * (size_t)in_pitch, sizeof(float2) * (size_t)n, S, hipMemcpyDeviceToDevice, s));
+    if (!dc_list.empty()) {  // DCRemoval::process: CIir high-pass 10 Hz, exact carried state (its pole sits at 1 - 3e-6 .. 3e-5)
+        const long long nsub = (n + kSub - 1) / kSub;
+        launch(k_iir_scan<0, 1>, dim3(1, (unsigned)dc_list.size()), dim3(64), s, (const float2 *)d_buf, cap, d_buf, cap, n, dc, (const double *)d_dc_state,
+               d_dc_state, (int)nsub, -1, (const int *)d_dc_list);
+    }
+    if (iq_any) launch(k_iq_balance, dim3(cdiv(n / nf, 64), S), dim3(64), s, d_buf, cap, (int)nf, n / nf, (const double2 *)d_iq);
+    if (nb_any) launch(k_noise_blank, dim3(cdiv(S, 64)), dim3(64), s, d_buf, cap, n, d_nb, (int)S);
+    PG_HIP(hipGetLastError());
+    *out = d_buf;
+    *out_pitch = cap;
+    return 0;
+}
+
+int AnfCore::init(uint32_t channels)
+{
+    C = channels;
+    on.assign(C, 0);
+    return 0;
+}
+void AnfCore::release()
+{
+    if (d_state) (void)hipFree(d_state);
+    if (d_list) (void)hipFree(d_list);
+    d_state = nullptr;
+    d_list = nullptr;
+}
+int AnfCore::set(uint32_t ch, bool enable)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (!d_state) {
+        PG_HIP(hipMalloc((void **)&d_state, sizeof(AnfState) * C));
+        PG_HIP(hipMemset(d_state, 0, sizeof(AnfState) * C));  // new CPX[] coefficients and the delay line start at zero
+        PG_HIP(hipMalloc((void **)&d_list, sizeof(int) * C));
+    }
+    on[ch] = enable ? 1 : 0;
+    dirty = true;
+    return 0;
+}
+int AnfCore::apply(hipStream_t s)
+{
+    if (!dirty) return 0;
+    list.clear();
+    for (uint32_t c = 0; c < C; c++) if (on[c]) list.push_back((int)c);
+    PG_HIP(hipStreamSynchronize(s));
+    if (!list.empty()) PG_HIP(hipMemcpy(d_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+    dirty = false;
+    return 0;
+}
+int AnfCore::run(hipStream_t s, float2 *buf, long long pitch, long long n)
+{
+    if (list.empty()) return 0;
+    launch(k_anf, dim3((unsigned)list.size()), dim3(64), s, buf, pitch, n, d_state, (const int *)d_list);
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ResampCore
 // ------------------------------------------------------------------------------------------------
 int ResampCore::init(uint32_t channels, uint32_t frame, double rate, uint32_t frames_per_call)

@@ -138,6 +138,10 @@ static Biquad rbj(double f0, double q, double fs, int kind)
         b.b0 = A * ((1.0 - std::cos(w0)) / 2.0);
         b.b1 = A * (1.0 - std::cos(w0));
         b.b2 = b.b0;
+    } else if (kind == 2) {  // high-pass, iir.cpp:110-125
+        b.b0 = A * ((1.0 + std::cos(w0)) / 2.0);
+        b.b1 = -A * (1.0 + std::cos(w0));
+        b.b2 = b.b0;
     } else {          // band-reject, iir.cpp:152-167
         b.b0 = A;
         b.b1 = A * (-2.0 * std::cos(w0));
@@ -147,6 +151,7 @@ static Biquad rbj(double f0, double q, double fs, int kind)
 }
 Biquad biquad_lowpass(double f0, double q, double fs) { return rbj(f0, q, fs, 0); }
 Biquad biquad_notch(double f0, double q, double fs) { return rbj(f0, q, fs, 1); }
+Biquad biquad_highpass(double f0, double q, double fs) { return rbj(f0, q, fs, 2); }
 
 double blackman_harris(uint32_t n, std::vector<double> &w)
 {

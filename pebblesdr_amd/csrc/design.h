@@ -45,6 +45,7 @@ std::vector<double> fir_lowpass(int force_taps, double scale, double astop, doub
 struct Biquad { double b0, b1, b2, a1, a2; };
 Biquad biquad_lowpass(double f0, double q, double fs);
 Biquad biquad_notch(double f0, double q, double fs);
+Biquad biquad_highpass(double f0, double q, double fs);
 
 // WindowFunction BLACKMANHARRIS, pebblelib/windowfunction.cpp:214-235; returns coherentGain = sum/N
 double blackman_harris(uint32_t n, std::vector<double> &w);

@@ -470,4 +470,125 @@ static __global__ __launch_bounds__(256) void k_resample(const float2 *__restric
     out[(long long)c * out_pitch + fr.out_offset + k] = make_float2((float)ar, (float)ai);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pre-chain conditioners (receiver.cpp:814-823) and the noise filter (receiver.cpp:974).  All are default-off in the
+// reference and serial in time by construction (adaptive / thresholded feedback); they run one lane per independent
+// unit so that banks of streams parallelise, and exist for functional parity, not for the throughput path.
+// ------------------------------------------------------------------------------------------------
+// IQBalance::ProcessBlock (application/iqbalance.cpp:65-86): the adaptive terms t1, t2 restart at zero every block,
+// so every (stream, frame) is independent: one lane each.  grid (ceil(frames/64), streams), block 64.
+static __global__ __launch_bounds__(64) void k_iq_balance(float2 *__restrict__ buf, long long pitch, int nf, long long n_frames,
+                                                          const double2 *__restrict__ factors /* [stream] (gain, phase); gain < 0: off */)
+{
+    const long long f = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (f >= n_frames) return;
+    const double2 gp = factors[s];
+    if (gp.x < 0) return;
+    float2 *x = buf + (long long)s * pitch + f * nf;
+    double t1r = 0, t1i = 0, t2r = 0, t2i = 0;
+    const float mu = 0.0025f;
+    const double sc = 1.0 - mu * 0.000001;
+    for (int i = 0; i < nf; i++) {
+        const float2 v = x[i];
+        const double orr = (double)v.x * gp.x;
+        const double oi = (double)v.y + ((double)v.x * gp.y);
+        t1r = orr + (t2r * orr + t2i * oi);
+        t1i = oi + (t2i * orr - t2r * oi);
+        const double sqr = t1r * t1r - t1i * t1i, sqi = 2.0 * t1r * t1i;
+        t2r = t2r * sc - sqr * mu;
+        t2i = t2i * sc - sqi * mu;
+        x[i] = make_float2((float)t1r, (float)t1i);
+    }
+}
+
+// NoiseBlanker::ProcessBlock then ProcessBlock2 (application/noiseblanker.cpp:45-97), state carried across calls.
+struct NbState {
+    float nb_avg_mag, nb2_avg_mag;
+    int spike_count, head, last, flags;  // flags: 1 NB1 on, 2 NB2 on
+    double nb2_avg[2];
+    float2 delay[8];                     // DelayLine(8, 2)
+};
+static __global__ __launch_bounds__(64) void k_noise_blank(float2 *__restrict__ buf, long long pitch, long long n, NbState *__restrict__ st, int n_streams)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_streams) return;
+    NbState b = st[s];
+    if (!(b.flags & 3)) return;
+    float2 *x = buf + (long long)s * pitch;
+    const double threshold = 3.3;
+    for (long long i = 0; i < n; i++) {
+        float2 v = x[i];
+        if (b.flags & 1) {
+            const float mag = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
+            b.delay[b.head] = v;
+            b.last = b.head;
+            b.head = b.head == 0 ? 7 : b.head - 1;
+            b.nb_avg_mag = (float)((0.999 * (double)b.nb_avg_mag) + (0.001 * (double)mag));
+            if (b.spike_count == 0 && (double)mag > ((double)b.nb_avg_mag * threshold)) b.spike_count = 7;
+            if (b.spike_count > 0) {
+                v = make_float2(0.f, 0.f);
+                b.spike_count--;
+            } else {
+                v = b.delay[(b.last + 2) % 8];
+            }
+        }
+        if (b.flags & 2) {
+            const float mag = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
+            b.nb2_avg[0] = b.nb2_avg[0] * 0.75 + (double)v.x * 0.25;
+            b.nb2_avg[1] = b.nb2_avg[1] * 0.75 + (double)v.y * 0.25;
+            b.nb2_avg_mag = (float)(0.999 * (double)b.nb2_avg_mag + 0.001 * (double)mag);
+            if ((double)mag > (threshold * (double)b.nb2_avg_mag)) v = make_float2((float)b.nb2_avg[0], (float)b.nb2_avg[1]);
+        }
+        x[i] = v;
+    }
+    st[s] = b;
+}
+
+// NoiseFilter::ProcessBlock (ANF: 45-tap leaky LMS predictor on a 64-sample delay, application/noisefilter.cpp:31-88).
+// One WAVE per listed channel: lane j < 45 owns coefficient j and reads delayed sample j; the two dot products are
+// wave reductions.  The delay line lives in the state block (global memory, L2-resident).
+constexpr int kAnfTaps = 45, kAnfDelaySize = 512, kAnfDelay = 64;
+struct AnfState {
+    double coeff[2 * kAnfTaps];
+    float2 delay[kAnfDelaySize];
+    int head, last, pad_[2];
+};
+static __global__ __launch_bounds__(64) void k_anf(float2 *__restrict__ buf, long long pitch, long long n, AnfState *__restrict__ st,
+                                                   const int *__restrict__ chan_list)
+{
+    const int c = chan_list[blockIdx.x], lane = threadIdx.x;
+    float2 *x = buf + (long long)c * pitch;
+    AnfState *a = st + c;
+    const bool tap = lane < kAnfTaps;
+    double cr = tap ? a->coeff[2 * lane] : 0.0, ci = tap ? a->coeff[2 * lane + 1] : 0.0;
+    int head = a->head, last = a->last;
+    const double rate = 0.01, leakage = 0.00001, scl1 = 1.0 - rate * leakage;
+    for (long long i = 0; i < n; i++) {
+        const float2 in = x[i];
+        if (lane == 0) a->delay[head] = in;
+        last = head;
+        head = head == 0 ? kAnfDelaySize - 1 : head - 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float2 d = tap ? a->delay[(last + kAnfDelay + lane) % kAnfDelaySize] : make_float2(0.f, 0.f);
+        const double dr = (double)d.x, di = (double)d.y;
+        double sosr = dr * dr, sosi = di * di, accr = cr * dr, acci = ci * di;
+        // the reference sums j = 0..44 in order; a tree sum differs in the last bits only (the result is stored as float)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            sosr += __shfl_xor(sosr, m); sosi += __shfl_xor(sosi, m);
+            accr += __shfl_xor(accr, m); acci += __shfl_xor(acci, m);
+        }
+        if (lane == 0) x[i] = make_float2((float)(accr * 1.25), (float)(acci * 1.25));
+        const double er = ((double)in.x - accr) * (rate / (sosr + 1e-10));
+        const double ei = ((double)in.y - acci) * (rate / (sosi + 1e-10));
+        cr = cr * scl1 + er * dr;
+        ci = ci * scl1 + ei * di;
+    }
+    if (tap) { a->coeff[2 * lane] = cr; a->coeff[2 * lane + 1] = ci; }
+    if (lane == 0) { a->head = head; a->last = last; }
+}
+
 }  // namespace pg

@@ -144,6 +144,16 @@ int pebblegpu_set_agc(pebblegpu_receiver *h, uint32_t channel, int agc_mode, int
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
     return h->rx.set_agc(channel, agc_mode, threshold);
 }
+int pebblegpu_set_conditioners(pebblegpu_receiver *h, uint32_t stream, int flags, double iq_gain, double iq_phase)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_conditioners(stream, flags, iq_gain, iq_phase);
+}
+int pebblegpu_set_noise_filter(pebblegpu_receiver *h, uint32_t channel, int on)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_noise_filter(channel, on != 0);
+}
 int pebblegpu_set_demod_mode(pebblegpu_receiver *h, uint32_t channel, int mode)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");

@@ -177,6 +177,43 @@ struct AgcCore {
     bool list_dirty = false;
 };
 
+// ---- DCRemoval, IQBalance, NoiseBlanker on the input streams (receiver.cpp:814-823) and NoiseFilter/ANF (receiver.cpp:974) ----
+struct ConditionCore {
+    uint32_t S = 0, nf = 0;
+    double fs = 0;
+    long long cap = 0;
+    struct Host { int flags = 0; double gain = 1, phase = 0; };
+    std::vector<Host> host;
+    bool any = false, dirty = false;
+    float2 *d_buf = nullptr;          // [S][cap] conditioned copy of the input (allocated on first enable)
+    double *d_dc_state = nullptr;     // [S][1][2][2]
+    int *d_dc_list = nullptr;
+    std::vector<int> dc_list;
+    double2 *d_iq = nullptr;          // [S] (gain, phase), gain < 0: off
+    struct NbState *d_nb = nullptr;   // [S]
+    ScanParams<1> dc;
+    bool iq_any = false, nb_any = false;
+    int init(uint32_t streams, uint32_t frame, double sample_rate, long long max_n);
+    void release();
+    int set(uint32_t stream, int flags, double gain, double phase);
+    int apply(hipStream_t s);
+    // copies d_in to the internal buffer and runs the enabled steps on it; *out = what the rest of the call should read
+    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n, const float2 **out, long long *out_pitch);
+};
+struct AnfCore {
+    uint32_t C = 0;
+    struct AnfState *d_state = nullptr;
+    int *d_list = nullptr;
+    std::vector<int> list;
+    std::vector<char> on;
+    bool dirty = false;
+    int init(uint32_t channels);
+    void release();
+    int set(uint32_t ch, bool enable);
+    int apply(hipStream_t s);
+    int run(hipStream_t s, float2 *buf, long long pitch, long long n);
+};
+
 // ---- CFractResampler (complex), pebblelib/fractresampler.cpp ----
 struct ResampCore {
     uint32_t C = 0, nf = 0;
@@ -229,6 +266,8 @@ public:
     int set_bandpass(uint32_t ch, double lo, double hi);
     int set_mode(uint32_t ch, int mode);
     int set_agc(uint32_t ch, int mode, int threshold);
+    int set_conditioners(uint32_t stream, int flags, double iq_gain, double iq_phase);
+    int set_noise_filter(uint32_t ch, bool on);
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();
@@ -276,6 +315,8 @@ private:
     PllCore nfm_, sam_;
     WfmCore wfmc_;
     AgcCore agc_;
+    ConditionCore cond_;
+    AnfCore anf_;
     ResampCore resamp_;
     SpectrumCore spec_;
     float2 *d_stage_in_ = nullptr;

@@ -56,9 +56,11 @@ int Receiver::create(const pebblegpu_config *cfg)
         // Demod_SAM / Demod_NFM objects also exist in every Receiver (demod.cpp:63-64); their buffers are allocated on first use
         pll_cap_ = nd_max;
         if (int rc = agc_.init(C, (double)demod_rate_int)) return rc;  // AGC(m_demodSampleRate, m_demodFrames), receiver.cpp:264
+        if (int rc = anf_.init(C)) return rc;
     } else {
         if (int rc = wfmc_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_WFM(m_inputWfmSampleRate), demod.cpp:65
     }
+    if (int rc = cond_.init(S, nf, fs, max_n)) return rc;
     audio_rate = cfg->audio_rate;
     if (audio_rate) {
         // resampRate = (m_demodSampleRate*1.0) / (m_audioOutRate*1.0), the int members (receiver.cpp:901,994)
@@ -83,7 +85,7 @@ Receiver::~Receiver()
     (void)hipSetDevice(device);
     if (stream_) (void)hipStreamSynchronize(stream_);
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
-    agc_.release(); resamp_.release();
+    agc_.release(); resamp_.release(); cond_.release(); anf_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
     if (d_smeter) (void)hipFree(d_smeter);
     if (d_sm_bins) (void)hipFree(d_sm_bins);
@@ -131,6 +133,21 @@ int Receiver::enable_smeter(bool on)
     }
     smeter_on = on;
     return 0;
+}
+
+int Receiver::set_conditioners(uint32_t stream, int flags, double iq_gain, double iq_phase)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    PG_HIP(hipSetDevice(device));
+    return cond_.set(stream, flags, iq_gain, iq_phase);
+}
+
+int Receiver::set_noise_filter(uint32_t ch, bool on)
+{
+    if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the WFM branch has no noise filter step (receiver.cpp:854-901)");
+    std::lock_guard<std::mutex> g(mu_);
+    PG_HIP(hipSetDevice(device));
+    return anf_.set(ch, on);
 }
 
 int Receiver::set_agc(uint32_t ch, int mode, int threshold)
@@ -202,6 +219,7 @@ int Receiver::apply_controls()
         }
     }
     if (int rc = agc_.apply(stream_)) return rc;
+    if (int rc = anf_.apply(stream_)) return rc;
     if (am_list_dirty_) {
         std::vector<int> l, ls, ln;
         for (uint32_t ch = 0; ch < C; ch++) {
@@ -230,7 +248,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (with_spectrum && (!bins || n % nf != 0 || n > (uint64_t)max_sf * superframe))
         return fail(PEBBLEGPU_E_SIZE, "spectrum needs whole frames of %u samples within capacity", nf);
     if (int rc = apply_controls()) return rc;
-    const long long in_pitch = (long long)n;
+    if (int rc = cond_.apply(stream_)) return rc;
+    long long in_pitch = (long long)n;
+    // DCRemoval, IQBalance, NoiseBlanker 1/2 on the raw streams, ahead of the spectrum and the mixer (receiver.cpp:814-823)
+    if (int rc = cond_.run(stream_, d_iq, in_pitch, (long long)n, &d_iq, &in_pitch)) return rc;
     hipEvent_t *ev = tm.slot();
     tm.calls++;
     PG_HIP(hipEventRecord(ev[0], stream_));
@@ -257,6 +278,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (!wfm) {
         if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
         if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
+        if (int rc = anf_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
         if (int rc = agc_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
         if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
@@ -298,6 +320,8 @@ int Receiver::process_iq(const double *iq, uint16_t n, double *audio_out, uint32
     if (!iq || !n_audio) return fail(PEBBLEGPU_E_INVALID, "null argument");
     if (n != nf) return fail(PEBBLEGPU_E_SIZE, "process_iq takes frames of %u samples", nf);
     if (S != 1) return fail(PEBBLEGPU_E_UNSUPPORTED, "process_iq feeds one stream; this bank has %u", S);
+    if (cond_.any || cond_.dirty)
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "the input conditioners run on the batched device path (pebblegpu_receiver_process) only");
     PG_HIP(hipSetDevice(device));
     if (!d_stage_in_) PG_HIP(hipMalloc((void **)&d_stage_in_, sizeof(float2) * superframe));
     h_frame_.resize((size_t)nf * 2);

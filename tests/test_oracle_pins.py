@@ -314,3 +314,47 @@ def test_fd_estimate_window_arithmetic(oracle_mod):
     assert peak == -30.0 and floor == -100.0 and abs(snr - 70.0) < 1e-9
     assert abs(avg - 10 * np.log10((7 * 1e-3 + 10 * 1e-10) / 16)) < 1e-9
 
+
+def test_anf_is_ill_conditioned_on_band_limited_input(oracle_mod):
+    """NoiseFilter (45-tap leaky NLMS) behind the band-pass: its input occupies a few per cent of the band, the input
+    correlation matrix is nearly singular, and the reference's OWN output moves by ~1e-4 for a 1e-8 white perturbation
+    of that input (amplification ~1e4) -- while on a full-band input the same perturbation stays at the 1e-7 level.
+    This is why the in-chain GPU comparison for the ANF carries a looser bar (tests/test_parity_gpu.py)."""
+    O = oracle_mod
+    fs = 64000.0
+    rng = np.random.RandomState(2)
+    t = np.arange(6144) / fs
+    narrow = 0.15 * np.exp(2j * np.pi * 1000 * t) + 0.09 * np.exp(2j * np.pi * 2200 * t)  # what a 300..3000 Hz band-pass leaves
+    wide = narrow + 0.03 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))
+    pert = 1e-8 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))
+
+    def moved(x):
+        y0, y1 = O.Anf().process(x), O.Anf().process(x + pert)
+        return np.sqrt(np.mean(np.abs(y1 - y0) ** 2)) / np.sqrt(np.mean(np.abs(y0) ** 2))
+    assert moved(narrow) > 1e-5
+    assert moved(wide) < 1e-6
+
+
+def test_conditioner_restatements_closed_forms(oracle_mod):
+    """IQBalance with unit gain / zero phase on a clean tone leaves it untouched to first order (t2 stays ~mu*|x|^2);
+    NoiseBlanker 1 zeroes exactly 7 samples from a spike on and otherwise delays by 2; NoiseBlanker 2 replaces a spike by
+    the running average; DCRemoval (high-pass 10 Hz) removes a constant."""
+    O = oracle_mod
+    fs = 2048000.0
+    t = np.arange(4096) / fs
+    x = 0.1 * np.exp(2j * np.pi * 50e3 * t)
+    y = O.iq_balance(x, 1.0, 0.0)
+    assert np.abs(y - x).max() < 1e-3 and np.abs(y[:3] - x[:3]).max() < 1e-4
+    nb = O.NoiseBlanker(); nb.enable(1)
+    z = x.copy(); z[2000] += 5.0
+    o = nb.process(z, 1)
+    zeros = np.flatnonzero(o == 0)
+    assert list(zeros[zeros >= 2000]) == list(range(2000, 2007))
+    assert np.allclose(o[2100:2200], z[2098:2198])
+    nb2 = O.NoiseBlanker(); nb2.enable(2)
+    o2 = nb2.process(z, 2)
+    assert abs(o2[2000]) < 2.0 and np.array_equal(o2[2500:2600], z[2500:2600])
+    dc = O.Iir("hp", 10, 0.7071, fs)
+    d = dc.process(np.full(2000000, 0.25 + 0.1j))
+    assert abs(d[-1]) < 1e-3 and abs(d[0] - (0.25 + 0.1j)) < 1e-4
+

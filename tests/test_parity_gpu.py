@@ -702,6 +702,68 @@ def test_signal_strength_per_frame(gpu_lib, oracle_mod):
         plain.enable_signal_strength(True)  # no spectrum to measure on
 
 
+# ------------------------------------------------------------------------------------------------
+# DCRemoval, IQBalance, NoiseBlanker 1/2 ahead of the spectrum and the mixer; NoiseFilter (ANF)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", [1, 2, 4, 8, 15])
+def test_input_conditioners(gpu_lib, oracle_mod, flags):
+    """Each conditioner alone and all four together (reference order), on a stream with a DC offset and three spikes:
+    audio and spectrum against the oracle chain over 3 super-frames in 2 calls (state carries across calls)."""
+    import pebblesdr_amd as P
+    fs, n, bins = 2048000, 2048, 4096
+    ref = oracle_mod.Receiver(fs, n, bins); ref.set_mode(oracle_mod.USB); ref.set_mixer(100e3); ref.set_filter(300, 3000)
+    ref.set_conditioners(flags, 1.02, 0.03)
+    rx = P.ReceiverBank(fs, 1, True, False, bins, max_superframes=2)
+    rx.set_mode(0, P.DM_USB); rx.set_mixer(0, 100e3); rx.set_bandpass(0, 300, 3000); rx.set_conditioners(0, flags, 1.02, 0.03)
+    sf = rx.superframe
+    x = tones(fs, 3 * sf, [(0.05, 101e3), (0.02, -250e3)]) + lcg_noise(3 * sf, 5, 1e-3) + 0.01
+    x[5000] += 2.0; x[70000:70003] += 1.5j; x[150000] -= 3.0
+    outs = [rx.process(x[lo:hi]) for lo, hi in ((0, sf), (sf, 3 * sf))]
+    g = np.concatenate([o[0] for o in outs], axis=1)[0]
+    gs = np.concatenate([o[1] for o in outs], axis=1)[0]
+    want, ws = [], []
+    for f in range(3 * sf // n):
+        a, sp = ref.process(x[f * n:(f + 1) * n])
+        want.append(a); ws.append(sp)
+    assert rel_rms(g, np.concatenate(want)) <= TOL
+    for f in range(1, len(ws)):
+        assert db_err(gs[f], ws[f]) <= TOL_DB
+    with pytest.raises(P.PebbleGpuError) as e:
+        rx.process_iq(x[:n].astype(np.complex128))  # the conditioners are on the batched path only
+    assert e.value.code == -6
+
+
+def test_noise_filter_anf(gpu_lib, oracle_mod):
+    """The ANF kernel against the oracle's ANF on IDENTICAL input (the device's own band-pass output, from a second
+    bank): <= 1e-6.  In the chain the algorithm is ill-conditioned -- its input is band-limited to 4 % of the band, and
+    a 1e-8 white perturbation of it moves the reference's own output by 1e-4 (test_oracle_pins) -- so against the oracle
+    CHAIN, whose band-pass output differs by ~1e-7, the bar is 5e-3 with the first 300 samples (before the adaptation
+    has wandered) at 1e-5."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+
+    def bank(anf):
+        b = P.ReceiverBank(fs, 1, True, False, 0, max_superframes=2)
+        b.set_mode(0, P.DM_USB); b.set_mixer(0, 100e3); b.set_bandpass(0, 300, 3000)
+        if anf:
+            b.set_noise_filter(0, True)
+        return b
+    a, b = bank(True), bank(False)
+    sf = a.superframe
+    x = tones(fs, 3 * sf, [(0.05, 101e3), (0.03, 102.2e3)]) + lcg_noise(3 * sf, 5, 1e-2)
+    ga = np.concatenate([a.process(x[:sf])[0], a.process(x[sf:])[0]], axis=1)[0]
+    gb = np.concatenate([b.process(x[:sf])[0], b.process(x[sf:])[0]], axis=1)[0]
+    same_input = oracle_mod.Anf().process(gb.astype(np.complex128))
+    assert rel_rms(ga, same_input) <= 1e-6
+    ref = oracle_mod.Receiver(fs, n, 0); ref.set_mode(oracle_mod.USB); ref.set_mixer(100e3); ref.set_filter(300, 3000); ref.set_anf(True)
+    r = np.concatenate([ref.process(x[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(3 * sf // n)])
+    assert rel_rms(ga, r) <= 5e-3
+    assert np.abs(ga[:300] - r[:300]).max() <= 1e-5 * np.abs(r).max()
+    w = P.ReceiverBank(fs, 1, True, True, 0)
+    with pytest.raises(P.PebbleGpuError):
+        w.set_noise_filter(0, True)
+
+
 def test_error_paths(gpu_lib):
     import pebblesdr_amd as P
     rx = P.ReceiverBank(2048000, 2, True, False, 0)
