@@ -1135,7 +1135,7 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
     const dim3 grid(cdiv(F, G * groups), S), block(256);
     const float *pin = d_prev[parity];
     float *pout = d_prev[parity ^ 1];
-    if (bins == 2048) launch(k_spectrum<1>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
+    if (bins == 2048) launch(k_spectrum_1to1, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_tw_nf, pin, pout, sp);
     else if (bins == 4096) launch(k_spectrum<2>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
     else launch(k_spectrum<4>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
     parity ^= 1;

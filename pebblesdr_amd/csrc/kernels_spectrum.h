@@ -58,9 +58,15 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 
     for (int i = threadIdx.x; i < fft_tw_off(NF, NF); i += 256) tw_lds[i] = tw_nf[i];
 
-    float win[EL];  // window values of the slice this wave loads: constant over frames
+    // window values of the slice this wave loads: constant over frames, kept in registers when the slice is short
+    // (ZP = 4: 8 values); for longer slices they are re-read (L1-resident) when the slice is parked
+    constexpr bool WIN_REGS = EL <= 8;
+    float win[WIN_REGS ? EL : 1];
+    if (WIN_REGS) {
 #pragma unroll
-    for (int i = 0; i < EL; i++) win[i] = window[q * SL + lane + 64 * i];
+        for (int i = 0; i < EL; i++) win[i] = window[q * SL + lane + 64 * i];
+    }
+    const float *wq = window + q * SL + lane;
     const float2 tw_lane = cis_cycles(-(double)(lane * q) / (double)BINS);  // W_bins^{lane q}
     const float2 *bq = btab + q * E;                                         // W_bins^{64 m q}, m < E (wave-uniform)
 
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 #pragma unroll
             for (int i = 0; i < EL; i++) xn[i] = x[ff * NF + q * SL + lane + 64 * i];
 #pragma unroll
-            for (int i = 0; i < EL; i++) my[XOFF + lane + 64 * i] = cscale(xn[i], win[i]);
+            for (int i = 0; i < EL; i++) my[XOFF + lane + 64 * i] = cscale(xn[i], WIN_REGS ? win[i] : wq[64 * i]);
         }
     }
     __syncthreads();
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
         if (fetch) {
             float2 *xs = my + XOFF + ln;
 #pragma unroll
-            for (int i = 0; i < EL; i++) xs[64 * i] = cscale(xn[i], win[i]);
+            for (int i = 0; i < EL; i++) xs[64 * i] = cscale(xn[i], WIN_REGS ? win[i] : wq[64 * i]);
         }
         if (it >= 0 && live) {
             // the ZP waves of this frame interleave their slices: lane tg owns sub-bins j = tg + TG*i
@@ -168,6 +174,90 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
             }
         }
         __syncthreads();  // C: next frame parked, dB slices consumed
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bins == frame length (2048, no zero padding): every wave owns whole frames, so nothing is shared inside the workgroup --
+// no parked slices, no interleave, no barrier in the frame loop.  A wave loads its next frame into registers while it
+// transforms the current one and stores its dB bins itself (lane-contiguous).  grid (ceil(F / (4 G)), S), block 256.
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256, 2) void k_spectrum_1to1(const float2 *__restrict__ in, float *__restrict__ out,
+                                                                 const float *__restrict__ window, const float2 *__restrict__ tw_nf,
+                                                                 const float *__restrict__ prev_in, float *__restrict__ prev_out, SpectrumParams sp)
+{
+    constexpr int NF = 2048, E = NF / 64;
+    __shared__ float2 lds[4][FftLds<NF>::kSlots];
+    __shared__ float2 tw_lds[fft_tw_off(NF, NF)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.y, G = sp.frames_per_group;
+    const long long f0 = ((long long)blockIdx.x * 4 + wave) * G;
+    const float2 *x = in + (long long)s * sp.in_pitch;
+    float *y = out + (long long)s * sp.out_pitch;
+    float2 *my = lds[wave];
+    for (int i = threadIdx.x; i < fft_tw_off(NF, NF); i += 256) tw_lds[i] = tw_nf[i];
+    __syncthreads();
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
+    float pa[E];
+    float2 nxt[E];
+    {   // the first frame this wave transforms: f0 - 1 (its amplitudes seed the average), or frame 0 at the call boundary
+        const long long ff = f0 > 0 ? f0 - 1 : 0;
+        if (ff < sp.n_frames) {
+#pragma unroll
+            for (int m = 0; m < E; m++) nxt[m] = x[ff * NF + lane + 64 * m];
+        }
+    }
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        const bool live = f < sp.n_frames;
+        int ln = lane;
+        opaque(ln);
+        if (live && f < 0) {
+            const float *pp = prev_in + (long long)s * NF + ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) pa[m] = pp[64 * m];
+            continue;
+        }
+        if (!live) break;
+        float2 v[E];
+        {
+            const float *wp = window + ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) v[m] = cscale(nxt[m], wp[64 * m]);
+        }
+        if (it + 1 < G && f + 1 < sp.n_frames) {
+            const float2 *xp = x + (f + 1) * NF + ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) nxt[m] = xp[64 * m];
+        }
+        fft_regs<NF, +1, 64>(v, my, tw_lds, ln);
+        float mag[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) mag[m] = v[m].x * v[m].x + v[m].y * v[m].y;
+#pragma unroll
+        for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_sqrtf(mag[m]);
+        sched_fence();
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const float a = mag[m] + pa[m];
+            pa[m] = mag[m];
+            mag[m] = a;
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_logf(mag[m]);
+        sched_fence();
+        if (it >= 0) {
+            float *yf = y + f * (long long)NF;
+#pragma unroll
+            for (int m = 0; m < E; m++)  // bin k = ln + 64 m unfolds to (k + NF/2) mod NF (fft.cpp:207-213)
+                yf[(ln + 64 * m + NF / 2) & (NF - 1)] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);
+        }
+        if (f == sp.n_frames - 1) {
+            float *pp = prev_out + (long long)s * NF + ln;
+#pragma unroll
+            for (int m = 0; m < E; m++) pp[64 * m] = pa[m];
+        }
     }
 }
 
