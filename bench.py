@@ -227,7 +227,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(k_ms, 4),
                          "rest_of_chain_ms": round(float(np.mean(chain_ms)), 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
