@@ -1083,6 +1083,26 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
         }
     PG_HIP(hipMalloc((void **)&d_btab, sizeof(float2) * bt.size()));
     PG_HIP(hipMemcpy(d_btab, bt.data(), sizeof(float2) * bt.size(), hipMemcpyHostToDevice));
+    if (bins == 8192 && !big) {
+        std::vector<float2> b2(4 * 16), t2((size_t)kTw128Count);
+        for (int q = 0; q < 4; q++)
+            for (int m = 0; m < 16; m++) {
+                const double a = -design::kTwoPi * (double)((128 * m * q) % 8192) / 8192.0;
+                b2[q * 16 + m] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        auto W = [](long long idx) {
+            const double a = -design::kTwoPi * (double)(idx % 2048) / 2048.0;
+            return make_float2((float)std::cos(a), (float)std::sin(a));
+        };
+        for (int k = 0; k < 16; k++)
+            for (int e = 0; e < 3; e++) t2[kTw128B + e * 16 + k] = W((long long)(16 * k) << e);
+        for (int k = 0; k < 128; k++)
+            for (int e = 0; e < 4; e++) t2[kTw128C + e * 128 + k] = W((long long)k << e);
+        PG_HIP(hipMalloc((void **)&d_btab128, sizeof(float2) * b2.size()));
+        PG_HIP(hipMemcpy(d_btab128, b2.data(), sizeof(float2) * b2.size(), hipMemcpyHostToDevice));
+        PG_HIP(hipMalloc((void **)&d_tw128, sizeof(float2) * t2.size()));
+        PG_HIP(hipMemcpy(d_tw128, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+    }
     scale = (float)(1.0 / (cg * (double)nf));  // /coherentGain then /maxBinPower, fft.cpp:347,355
     if (int rc = make_twiddles(2048, &d_tw_nf)) return rc;
     for (int i = 0; i < 2; i++) {
@@ -1093,9 +1113,9 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y};
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128};
     for (void *q : p) if (q) (void)hipFree(q);
-    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr;
+    d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr; d_btab128 = d_tw128 = nullptr;
     y_cap = 0;
 }
 int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out)
@@ -1126,6 +1146,20 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         PG_HIP(hipGetLastError());
         return 0;
     }
+    if (bins == 8192) {
+        // two-wave transforms, one frame chain per 512-thread workgroup; all workgroups resident at once (2 per CU on 256
+        // CUs) when the batch allows: every chain recomputes one frame, so longer chains also mean less repeated work
+        long long G8 = (F * (long long)S) / 512;
+        G8 = G8 < 1 ? 1 : (G8 > 32 ? 32 : G8);
+        sp.frames_per_group = (int)G8;
+        sp.scale = scale;
+        sp.out_pitch = F * (long long)bins;
+        launch(k_spectrum_t128, dim3(cdiv(F, G8), S), dim3(512), s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
+               (const float *)d_prev[parity], d_prev[parity ^ 1], sp);
+        parity ^= 1;
+        PG_HIP(hipGetLastError());
+        return 0;
+    }
     const int groups = 4 / (int)(bins / nf);  // wave groups (frames in flight) per workgroup
     long long G = (F * (long long)S) / (1024 * groups);  // aim for ~1024 workgroups; each group recomputes one extra frame
     G = G < 1 ? 1 : (G > 16 ? 16 : G);
@@ -1137,7 +1171,7 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
     float *pout = d_prev[parity ^ 1];
     if (bins == 2048) launch(k_spectrum_1to1, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_tw_nf, pin, pout, sp);
     else if (bins == 4096) launch(k_spectrum<2>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
-    else launch(k_spectrum<4>, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float2 *)d_tw_nf, pin, pout, sp);
+    else return fail(PEBBLEGPU_E_UNSUPPORTED, "no spectrum kernel for %u bins", bins);
     parity ^= 1;
     PG_HIP(hipGetLastError());
     return 0;

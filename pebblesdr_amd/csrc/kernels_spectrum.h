@@ -28,6 +28,7 @@
 // Algorithmic bytes per frame: 8*NF + 4*bins.
 #pragma once
 #include "fft_lds.h"
+#include "fft_t128.h"
 #include "params.h"
 
 namespace pg {
@@ -174,6 +175,127 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
             }
         }
         __syncthreads();  // C: next frame parked, dB slices consumed
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8192 bins on the two-wave transform (fft_t128.h): a workgroup of 512 = 4 transforms (q = 0..3) x 2 waves handles one
+// frame at a time; 16 points and 16 previous amplitudes per work-item instead of 32 + 32, so four waves fit a SIMD
+// (LDS: the same four 18 KiB exchange images, two workgroups per CU).  Seven workgroup barriers per frame.
+// grid (ceil(F / G), S), block 512.
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
+                                                                 const float *__restrict__ window, const float2 *__restrict__ btab128,
+                                                                 const float2 *__restrict__ tw128, const float *__restrict__ prev_in,
+                                                                 float *__restrict__ prev_out, SpectrumParams sp)
+{
+    constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP, XOFF = NF / 2;
+    constexpr int REGION = FftLds<NF>::kSlots;
+    __shared__ float2 lds[4][REGION];
+    __shared__ float2 tw_lds[kTw128Count];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wave >> 1, s = blockIdx.y;
+    const int G = sp.frames_per_group;
+    const long long f0 = (long long)blockIdx.x * G;
+    const float2 *x = in + (long long)s * sp.in_pitch;
+    float *y = out + (long long)s * sp.out_pitch;
+    float2 *my = lds[q];
+    float *stage = reinterpret_cast<float *>(my);
+    for (int i = tid; i < kTw128Count; i += 512) tw_lds[i] = tw128[i];
+    float win[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) win[i] = window[tid + 512 * i];
+    const int t0 = (wave & 1) * 64 + lane;                                   // work-item of its transform, 0..127
+    const float2 tw_lane = cis_cycles(-(double)(t0 * q) / (double)BINS);     // W_bins^{t q}
+    const float2 *bq = btab128 + q * E;                                      // W_bins^{128 m q}, m < 16 (wave-uniform)
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
+    float pa[E];
+    float2 xn[4];
+    auto park = [&](int tt) {  // sample n = tt + 512 i goes to region i, slot XOFF + tt
+#pragma unroll
+        for (int i = 0; i < 4; i++) lds[i][XOFF + tt] = cscale(xn[i], win[i]);
+    };
+    {
+        const long long ff = f0 > 0 ? f0 - 1 : 0;
+        if (ff < sp.n_frames) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) xn[i] = x[ff * NF + tid + 512 * i];
+            park(tid);
+        }
+    }
+    __syncthreads();
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        const bool live = f < sp.n_frames;   // workgroup-uniform
+        const bool xform = live && f >= 0;
+        int t = t0, td = tid;
+        opaque(t);
+        opaque(td);
+        const bool fetch = it + 1 < G && f + 1 < sp.n_frames && f >= 0;
+        if (fetch) {
+            const float2 *xp = x + (f + 1) * NF + td;
+#pragma unroll
+            for (int i = 0; i < 4; i++) xn[i] = xp[512 * i];
+        }
+        float2 v[E];
+        if (xform) {
+            const float2 *gp = &lds[0][XOFF + t];
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const float2 xv = gp[((128 * m) / SL) * REGION + (128 * m) % SL];
+                v[m] = cmul(bq[m], cmul(tw_lane, xv));
+            }
+        }
+        __syncthreads();  // A
+        if (live && f < 0) {
+            const float *pp = prev_in + (long long)s * BINS + ZP * t + q;
+#pragma unroll
+            for (int m = 0; m < E; m++) pa[m] = pp[ZP * 128 * m];
+        }
+        // every work-item of the workgroup takes the same path below (xform is uniform): the barriers inside match
+        if (xform) {
+            fft2048_t128(v, my, tw_lds, t, [] { __syncthreads(); });
+            float *st = stage + t;
+            float mag[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = v[m].x * v[m].x + v[m].y * v[m].y;
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_sqrtf(mag[m]);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const float a = mag[m] + pa[m];
+                pa[m] = mag[m];
+                mag[m] = a;
+            }
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_logf(mag[m]);
+#pragma unroll
+            for (int m = 0; m < E; m++) st[128 * m] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);
+            if (f == sp.n_frames - 1) {
+                float *pp = prev_out + (long long)s * BINS + ZP * t + q;
+#pragma unroll
+                for (int m = 0; m < E; m++) pp[ZP * 128 * m] = pa[m];
+            }
+        }
+        __syncthreads();  // B
+        if (fetch) park(td);
+        if (it >= 0 && live) {
+            const float *sp0 = reinterpret_cast<const float *>(lds[0]) + td;
+            float *yf = y + f * (long long)BINS;
+#pragma unroll
+            for (int i = 0; i < NF / 512; i++) {
+                const int j = td + 512 * i;
+                float4 d;
+                d.x = sp0[0 * (REGION * 2) + 512 * i];
+                d.y = sp0[1 * (REGION * 2) + 512 * i];
+                d.z = sp0[2 * (REGION * 2) + 512 * i];
+                d.w = sp0[3 * (REGION * 2) + 512 * i];
+                const int u = (ZP * j + BINS / 2) & (BINS - 1);
+                *reinterpret_cast<float4 *>(yf + u) = d;
+            }
+        }
+        __syncthreads();  // C
     }
 }
 

@@ -237,6 +237,7 @@ struct SpectrumCore {
     float *d_prev[2] = {nullptr, nullptr};
     float *d_window = nullptr;
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
+    float2 *d_btab128 = nullptr, *d_tw128 = nullptr;  // the same for the two-wave transform (fft_t128.h), 8192 bins
     // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): the [S][F][32][2048] intermediate
     bool big = false;
     float2 *d_Y = nullptr;
