@@ -221,7 +221,7 @@ def main():
             "config": {"workload": "configs[1]: 20 Msps int8-shape IQ, 1 channel/GPU, mixer+decimate(D=64)+WFM mono demod + 8192-bin SignalSpectrum per 2048-sample frame",
                        "samples_per_step_per_gpu": n, "frames_per_buffer": NF, "spectrum_bins": BINS,
                        "parallelism": "independent channel per GPU, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": "k_spectrum<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_spectrum_t128", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.superframes),
                          "measured_copy_peak_GBs": copy_gbps,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(k_ms, 4),

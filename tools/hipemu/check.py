@@ -46,6 +46,27 @@ def case_spectrum():
     return ok
 
 
+def case_spectrum_batch():
+    """several frames per call (frame chains, parking/prefetch, previous-frame average carried in registers and across calls)"""
+    ok = True
+    fs, n = 20_000_000, 2048
+    for bins in (2048, 4096, 8192):
+        rx = B.ReceiverBank(fs, 1, True, True, bins, max_superframes=1, lib=L)
+        ref = O.Spectrum(bins, 2048)
+        sf = rx.superframe
+        x = tones(fs, 2 * sf, [(10 ** (-10 / 20), 1234567.0), (10 ** (-40 / 20), -7000013.0)]) + lcg_noise(2 * sf, 1, 1e-4)
+        for call in range(2):
+            _, sp = rx.process(x[call * sf:(call + 1) * sf])
+            worst = 0.0
+            for f in range(sf // n):
+                r = ref.process(x[call * sf + f * n:call * sf + (f + 1) * n])
+                if call or f:
+                    m = r > -110
+                    worst = max(worst, float(np.abs(sp[0, f] - r)[m].max()))
+            ok &= report("spectrum batch bins=%d call %d (%d frames) max|dB|" % (bins, call, sf // n), worst, 0.05)
+    return ok
+
+
 def case_mixer():
     fs = 2.048e6
     x = tones(fs, 4 * 2048, [(0.5, 100e3), (0.2, -300e3)]) + lcg_noise(4 * 2048, 2, 1e-3)
@@ -242,7 +263,7 @@ def case_streambank():
     return ok
 
 
-CASES = {"audio_tail": case_audio_tail, "streambank": case_streambank, "spectrum": case_spectrum, "mixer": case_mixer, "decimator": case_decimator, "fastfir": case_fastfir,
+CASES = {"spectrum_batch": case_spectrum_batch, "audio_tail": case_audio_tail, "streambank": case_streambank, "spectrum": case_spectrum, "mixer": case_mixer, "decimator": case_decimator, "fastfir": case_fastfir,
          "demod": case_demod, "receiver": case_receiver}
 
 if __name__ == "__main__":
