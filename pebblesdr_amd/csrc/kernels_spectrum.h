@@ -10,7 +10,11 @@
 // i.e. ZP independent NF-point transforms of the windowed frame times a per-q twiddle -- log2(ZP) butterfly
 // passes over zeros are never executed.
 //
-// Mapping: one WAVE per (frame, q); the ZP waves of a frame form a group, a 256-item workgroup holds 4/ZP groups.
+// Three kernels share this scheme: k_spectrum<2> below (4096 bins: one wave per transform), k_spectrum_t128 (8192 bins: two
+// waves per transform, four waves per SIMD; measured ~8 % faster than the one-wave form at ZP = 4 and ~5 % slower at
+// ZP = 2, hence the split) and k_spectrum_1to1 (2048 bins: a wave owns whole frames).
+//
+// Mapping of k_spectrum<ZP>: one WAVE per (frame, q); the ZP waves of a frame form a group, a 256-item workgroup holds 4/ZP groups.
 //   * the group's waves load the NEXT frame once, cooperatively (each wave a 1/ZP slice, coalesced, issued before
 //     the current frame's transform so HBM latency hides under it), apply the window and park it in LDS;
 //   * each wave gathers the whole windowed frame from LDS in the FFT's strided register layout and applies its
