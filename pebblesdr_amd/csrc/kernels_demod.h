@@ -255,7 +255,7 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
         for (int g = 0; g < 4; g++) {
             blk -= 1;
             const float4 prev = nxt;
-            if (p0 + 4 * g + 4 < L4) nxt = blk[-1];
+            nxt = blk[-1];  // on the very last group this reads the 16 bytes in front of db (the end of lpb): in bounds, unused
             const float h0 = ht[4 * g], h1 = ht[4 * g + 1], h2 = ht[4 * g + 2], h3 = ht[4 * g + 3];
             a0 = fmaf(h0, cur.x, a0); a1 = fmaf(h0, cur.y, a1); a2 = fmaf(h0, cur.z, a2); a3 = fmaf(h0, cur.w, a3);
             a0 = fmaf(h1, prev.w, a0); a1 = fmaf(h1, cur.x, a1); a2 = fmaf(h1, cur.y, a2); a3 = fmaf(h1, cur.z, a3);
