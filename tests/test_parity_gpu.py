@@ -902,3 +902,39 @@ def test_full_size_configs3_512_channel_shard(gpu_lib, oracle_mod):
             want = ff.process(z)
         assert rel_rms(g[c], want) <= TOL
 
+
+def test_lifecycle_and_back_to_back_calls(gpu_lib, oracle_mod):
+    """Create/destroy many banks (no leak large enough to fail an allocation), then 40 calls queued back to back without
+    a host sync, with retunes, band changes and mode changes in between; the last super-frames must still match the
+    oracle that saw the same sequence."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    for _ in range(30):
+        b = P.ReceiverBank(fs, 4, True, False, 4096, max_superframes=4, audio_rate=11025)
+        b.close()
+    rx = P.ReceiverBank(fs, 1, True, False, 4096, max_superframes=1)
+    ref = oracle_mod.Receiver(fs, n, 4096)
+    sf = rx.superframe
+    calls = 40
+    x = tones(fs, calls * sf, [(0.05, 101e3), (0.04, -199e3), (0.03, 50e3)]) + lcg_noise(calls * sf, 9, 1e-3)  # each setting has a tone in band
+    buf = P.DeviceBuffer.from_array(P.binding.to_f32_iq(x))
+    plan = {0: ("mix", 100e3), 1: ("band", (300, 3000)), 2: ("mode", "USB"), 11: ("mix", -200e3), 12: ("mode", "AM"), 13: ("band", (-4000, 4000)),
+            25: ("mix", 51e3), 26: ("mode", "LSB"), 27: ("band", (-3000, -300))}
+    modes = {"USB": (P.DM_USB, oracle_mod.USB), "AM": (P.DM_AM, oracle_mod.AM), "LSB": (P.DM_LSB, oracle_mod.LSB)}
+    want = None
+    for k in range(calls):
+        if k in plan:
+            what, arg = plan[k]
+            if what == "mix":
+                rx.set_mixer(0, arg); ref.set_mixer(arg)
+            elif what == "band":
+                rx.set_bandpass(0, *arg); ref.set_filter(*arg)
+            else:
+                rx.set_mode(0, modes[arg][0]); ref.set_mode(modes[arg][1])
+        rx.process_device(buf.ptr + 8 * k * sf, sf)  # no sync between calls
+        want = np.concatenate([ref.process(x[k * sf + f * n:k * sf + (f + 1) * n])[0] for f in range(sf // n)])
+    got = rx.audio()[0]
+    assert rel_rms(got, want) <= TOL
+    with pytest.raises(P.PebbleGpuError):
+        rx.process_device(buf.ptr, 0)
+
