@@ -1134,7 +1134,8 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
             PG_HIP(hipMalloc((void **)&d_Y, sizeof(float2) * need));
             y_cap = need;
         }
-        long long G = (F * (long long)S * 8) / 2048;  // ~2048 workgroups before frames are chained in one group
+        // a chain that does not start at frame 0 recomputes one frame: prefer chains as long as keeps >= 512 workgroups
+        long long G = (F * (long long)S * 8) / 512;
         G = G < 1 ? 1 : (G > 16 ? 16 : G);
         sp.frames_per_group = (int)G;
         sp.scale = scale;
