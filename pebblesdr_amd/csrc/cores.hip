@@ -100,6 +100,23 @@ int make_twiddles(int n, float2 **d_tw)
     return 0;
 }
 
+int make_twiddles_t128(float2 **d_tw)
+{
+    // fft_t128.h: pass B W^{16k}, W^{32k}, W^{64k} (k < 16); pass C W^{k}, W^{2k}, W^{4k}, W^{8k} (k < 128); W = exp(-2 pi i / 2048)
+    std::vector<float2> t2((size_t)kTw128Count);
+    auto W = [](long long idx) {
+        const double a = -design::kTwoPi * (double)(idx % 2048) / 2048.0;
+        return make_float2((float)std::cos(a), (float)std::sin(a));
+    };
+    for (int k = 0; k < 16; k++)
+        for (int e = 0; e < 3; e++) t2[kTw128B + e * 16 + k] = W((long long)(16 * k) << e);
+    for (int k = 0; k < 128; k++)
+        for (int e = 0; e < 4; e++) t2[kTw128C + e * 128 + k] = W((long long)k << e);
+    PG_HIP(hipMalloc((void **)d_tw, sizeof(float2) * t2.size()));
+    PG_HIP(hipMemcpy(*d_tw, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // OscBank
 // ------------------------------------------------------------------------------------------------
@@ -396,13 +413,15 @@ int FastFirCore::init(uint32_t channels, uint32_t fft_size, uint32_t fir_size)
     if (taps < 2 || taps > fft_n) return fail(PEBBLEGPU_E_INVALID, "FastFIR taps must be in [2, fft size]");
     PG_HIP(hipMalloc((void **)&d_H, sizeof(float2) * (size_t)fft_n * C));
     PG_HIP(hipMemset(d_H, 0, sizeof(float2) * (size_t)fft_n * C));
+    if (fft_n == 2048) { if (int rc = make_twiddles_t128(&d_tw128)) return rc; }
     return make_twiddles((int)fft_n, &d_tw);
 }
 void FastFirCore::release()
 {
     if (d_H) (void)hipFree(d_H);
     if (d_tw) (void)hipFree(d_tw);
-    d_H = d_tw = nullptr;
+    if (d_tw128) (void)hipFree(d_tw128);
+    d_H = d_tw = d_tw128 = nullptr;
 }
 int FastFirCore::design(hipStream_t s, uint32_t ch, double lo, double hi, double offset, double rate, bool *ok)
 {
@@ -422,7 +441,7 @@ int FastFirCore::run(hipStream_t s, const HistBuf &in, long long n, float2 *out,
     if (n % L != 0) return fail(PEBBLEGPU_E_SIZE, "FastFIR input %lld is not a multiple of its block %lld", n, L);
     const dim3 grid((unsigned)(n / L), C), block(256);
     const float2 *no_tail = nullptr;
-    if (fft_n == 2048) launch(k_fastfir<2048>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
+    if (fft_n == 2048) launch(k_fastfir_t128, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail);
     else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     else launch(k_fastfir<8192>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     PG_HIP(hipGetLastError());
@@ -437,7 +456,7 @@ int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, fl
     if (n == 0) return 0;
     const dim3 grid((unsigned)(n / L), C), block(256);
     const float2 *tail = d_tail;
-    if (fft_n == 2048) launch(k_fastfir<2048>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
+    if (fft_n == 2048) launch(k_fastfir_t128, grid, dim3(128), s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail);
     else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
     else launch(k_fastfir<8192>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
     PG_HIP(hipGetLastError());
@@ -1084,24 +1103,15 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     PG_HIP(hipMalloc((void **)&d_btab, sizeof(float2) * bt.size()));
     PG_HIP(hipMemcpy(d_btab, bt.data(), sizeof(float2) * bt.size(), hipMemcpyHostToDevice));
     if (bins == 8192 && !big) {
-        std::vector<float2> b2(4 * 16), t2((size_t)kTw128Count);
+        std::vector<float2> b2(4 * 16);
         for (int q = 0; q < 4; q++)
             for (int m = 0; m < 16; m++) {
                 const double a = -design::kTwoPi * (double)((128 * m * q) % 8192) / 8192.0;
                 b2[q * 16 + m] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
-        auto W = [](long long idx) {
-            const double a = -design::kTwoPi * (double)(idx % 2048) / 2048.0;
-            return make_float2((float)std::cos(a), (float)std::sin(a));
-        };
-        for (int k = 0; k < 16; k++)
-            for (int e = 0; e < 3; e++) t2[kTw128B + e * 16 + k] = W((long long)(16 * k) << e);
-        for (int k = 0; k < 128; k++)
-            for (int e = 0; e < 4; e++) t2[kTw128C + e * 128 + k] = W((long long)k << e);
         PG_HIP(hipMalloc((void **)&d_btab128, sizeof(float2) * b2.size()));
         PG_HIP(hipMemcpy(d_btab128, b2.data(), sizeof(float2) * b2.size(), hipMemcpyHostToDevice));
-        PG_HIP(hipMalloc((void **)&d_tw128, sizeof(float2) * t2.size()));
-        PG_HIP(hipMemcpy(d_tw128, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+        if (int rc = make_twiddles_t128(&d_tw128)) return rc;
     }
     scale = (float)(1.0 / (cg * (double)nf));  // /coherentGain then /maxBinPower, fft.cpp:347,355
     if (int rc = make_twiddles(2048, &d_tw_nf)) return rc;

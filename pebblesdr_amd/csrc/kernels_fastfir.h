@@ -13,6 +13,7 @@
 // taps-1 = N/2 the overlap doubles the read to 16 B unless L2 serves the second touch).
 #pragma once
 #include "fft_lds.h"
+#include "fft_t128.h"
 
 namespace pg {
 
@@ -50,6 +51,51 @@ __global__ __launch_bounds__(256) void k_fastfir(const float2 *__restrict__ in, 
     for (int m = 0; m < E; m++) {
         const int i = tid + 256 * m;
         if (i >= overlap) y[i - overlap] = v[m];
+    }
+}
+
+// The 2048/1025 case (the reference's stock sizes) on the two-wave transform: a 128-item workgroup per block, 16 points
+// per work-item, barriers that only involve its own two waves.  The inverse transform is the forward one between two
+// conjugations.  grid (n / L, channels), block 128.
+static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__restrict__ in, long long in_pitch,
+                                                             float2 *__restrict__ out, long long out_pitch,
+                                                             const float2 *__restrict__ H, const float2 *__restrict__ tw128,
+                                                             int overlap /* taps-1 */, const float2 *__restrict__ tail)
+{
+    constexpr int N = 2048, E = 16;
+    __shared__ float2 lds[FftLds<N>::kSlots];
+    __shared__ float2 tw_lds[kTw128Count];
+    const int t = threadIdx.x, c = blockIdx.y;
+    const int L = N - overlap;
+    const long long b = blockIdx.x;
+    const float2 *x = in + (long long)c * in_pitch + b * L - overlap;  // first sample of [overlap | new]
+    const float2 *h = H + (long long)c * N;
+    for (int i = t; i < kTw128Count; i += 128) tw_lds[i] = tw128[i];
+    float2 v[E];
+    if (tail != nullptr && b == 0) {
+        const float2 *tl = tail + (long long)c * overlap;
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const int i = t + 128 * m;
+            v[m] = i < overlap ? tl[i] : x[i];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; m++) v[m] = x[t + 128 * m];
+    }
+    __syncthreads();
+    fft2048_t128(v, lds, tw_lds, t, [] { __syncthreads(); });
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const float2 p = cmul(h[t + 128 * m], v[m]);  // CpxMpy, fastfir.cpp:325-334
+        v[m] = make_float2(p.x, -p.y);                // conj: IFFT(z) = conj(FFT(conj(z))), unscaled (1/N is in the taps)
+    }
+    fft2048_t128(v, lds, tw_lds, t, [] { __syncthreads(); });  // (the forward transform ends behind a barrier: the image is free)
+    float2 *y = out + (long long)c * out_pitch + b * L;
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int i = t + 128 * m;
+        if (i >= overlap) y[i - overlap] = make_float2(v[m].x, -v[m].y);
     }
 }
 

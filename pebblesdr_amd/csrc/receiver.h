@@ -35,6 +35,7 @@ struct HistBuf {
 void fill_scan_section(ScanSection &s, int type, const double *c);
 int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
+int make_twiddles_t128(float2 **d_tw);
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
 int run_signal_strength(hipStream_t s, const float *d_spec, long long stream_pitch, int bins, long long n_frames, const SmBins *d_bins,
                         float4 *d_out, long long out_pitch, uint32_t channels);
@@ -88,6 +89,7 @@ struct DecimCore {
 struct FastFirCore {
     uint32_t C = 0, fft_n = 2048, taps = 1025;
     float2 *d_H = nullptr, *d_tw = nullptr;
+    float2 *d_tw128 = nullptr;   // 2048-point case: table of the two-wave transform (fft_t128.h)
     int init(uint32_t channels, uint32_t fft_size, uint32_t fir_size);
     void release();
     long long block_len() const { return (long long)fft_n - (taps - 1); }
