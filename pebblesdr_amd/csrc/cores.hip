@@ -296,16 +296,29 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
     first.gain = ns == 1 ? last_gain : 1.f;
     for (int p = 0; p < s0.ntaps; p++) first.h[p] = (float)design::halfband_taps(s0.design)[p];
     if (mixdec_lds_bytes(first) > 150 * 1024) return fail(PEBBLEGPU_E_UNSUPPORTED, "first-stage stride %u too wide for the LDS tile", s0.stride);
+    // a wide second stage is peeled off the fused cascade (see receiver.h)
+    wide = ns >= 3 && chain.stages[1].stride >= 8 && chain.stages[1].ntaps > 0;
+    size_t kfirst = 1;
+    if (wide) {
+        const design::Stage &w = chain.stages[1];
+        wide_taps = w.ntaps;
+        wide_stride = (int)w.stride;
+        std::vector<float> wt(kMaxTaps, 0.f);
+        for (int p = 0; p < w.ntaps; p++) wt[p] = (float)design::halfband_taps(w.design)[p];
+        PG_HIP(hipMalloc((void **)&d_wide_taps, sizeof(float) * kMaxTaps));
+        PG_HIP(hipMemcpy(d_wide_taps, wt.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
+        kfirst = 2;
+    }
     // the fused later stages
     memset(&casc, 0, sizeof(casc));
-    casc.nst = (int)ns - 1;
+    casc.nst = (int)(ns - kfirst);
     casc.gain = last_gain;
     long long halo0 = 0, prod = 1, later = 1;
-    for (size_t k = 1; k < ns; k++) {
+    for (size_t k = kfirst; k < ns; k++) {
         const design::Stage &st = chain.stages[k];
-        casc.ntaps[k - 1] = st.ntaps;
-        casc.stride[k - 1] = (int)st.stride;
-        for (int p = 0; p < st.ntaps; p++) casc.h[k - 1][p] = (float)design::halfband_taps(st.design)[p];
+        casc.ntaps[k - kfirst] = st.ntaps;
+        casc.stride[k - kfirst] = (int)st.stride;
+        for (int p = 0; p < st.ntaps; p++) casc.h[k - kfirst][p] = (float)design::halfband_taps(st.design)[p];
         halo0 += (long long)(st.ntaps - 1) * prod;  // look-back of the whole cascade, in stage-0 output samples
         prod *= st.stride;
         later *= st.stride;
@@ -334,8 +347,14 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
         if (int rc = buf0.alloc((int)C, last_hist, len0)) return rc;
     } else {
         if (halo0 > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "cascade look-back %lld too deep", halo0);
-        if (int rc = buf0.alloc((int)C, (int)halo0, len0)) return rc;
-        if (int rc = fin.alloc((int)C, last_hist, len0 / later)) return rc;
+        if (wide) {
+            if (int rc = buf0.alloc((int)C, wide_taps - 1, len0)) return rc;
+            if (int rc = buf1.alloc((int)C, (int)halo0, len0 / wide_stride)) return rc;
+            if (int rc = fin.alloc((int)C, last_hist, len0 / wide_stride / later)) return rc;
+        } else {
+            if (int rc = buf0.alloc((int)C, (int)halo0, len0)) return rc;
+            if (int rc = fin.alloc((int)C, last_hist, len0 / later)) return rc;
+        }
     }
     for (int i = 0; i < 2; i++) {
         PG_HIP(hipMalloc((void **)&d_hist_mixed[i], sizeof(float2) * kMaxTaps * C));
@@ -346,7 +365,10 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
 void DecimCore::release()
 {
     buf0.release();
+    buf1.release();
     fin.release();
+    if (d_wide_taps) (void)hipFree(d_wide_taps);
+    d_wide_taps = nullptr;
     for (int i = 0; i < 2; i++) {
         if (d_hist_mixed[i]) (void)hipFree(d_hist_mixed[i]);
         d_hist_mixed[i] = nullptr;
@@ -369,9 +391,16 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     hist_parity ^= 1;
     if (after_first) PG_HIP(hipEventRecord(after_first, s));
     len_out = len0;
+    const HistBuf *src = &buf0;
+    if (wide) {  // the peeled stride->=8 stage: every output reads its own taps-long window straight from buf0
+        len1 = len0 / wide_stride;
+        launch(k_fir_dec, dim3(cdiv(len1, 256), C), dim3(256), s, (const float2 *)buf0.data(), buf0.pitch, buf1.data(), buf1.pitch, len1, wide_stride,
+               (const float *)d_wide_taps, (const float *)nullptr, 0, (const int *)nullptr, wide_taps, 1.0f, 0, (const int *)nullptr);
+        src = &buf1;
+    }
     if (casc.nst > 0) {
         len_out = n / (long long)chain.total;
-        launch_lds(k_cascade, dim3(cdiv(len_out, casc.outb), C), dim3(256), casc_lds_bytes, s, (const float2 *)buf0.data(), buf0.pitch, fin.data(),
+        launch_lds(k_cascade, dim3(cdiv(len_out, casc.outb), C), dim3(256), casc_lds_bytes, s, (const float2 *)src->data(), src->pitch, fin.data(),
                    fin.pitch, len_out, casc);
     }
     PG_HIP(hipGetLastError());
@@ -380,6 +409,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
 void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
     if (buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
+    if (wide && buf1.hist > 0) jobs.push_back(TailJob{buf1.data(), buf1.pitch, len1, buf1.hist, 0, nullptr, 0});
     if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
 }
 

@@ -70,7 +70,14 @@ struct DecimCore {
     FirTaps first;                   // stage 0 (fused with the mixer)
     CascadeParams casc;              // stages 1.. (one fused kernel)
     size_t casc_lds_bytes = 0;
-    HistBuf buf0, fin;               // stage-0 output (head-room = cascade look-back), final output (absent for 1-stage chains)
+    HistBuf buf0, fin;               // stage-0 output (head-room = look-back of its reader), final output (absent for 1-stage chains)
+    // A second stage with a stride >= 8 (merged halfbands at high input rates) would make the fused cascade's tiles mostly
+    // halo: it runs as its own strided FIR (k_fir_dec) from buf0 into buf1, and the fused rest reads buf1.
+    bool wide = false;
+    int wide_taps = 0, wide_stride = 1;
+    float *d_wide_taps = nullptr;
+    HistBuf buf1;
+    long long len1 = 0;
     long long len0 = 0, len_out = 0; // lengths produced by the last run
     float2 *d_hist_mixed[2] = {nullptr, nullptr};  // [C][kMaxTaps]: mixed-sample history of stage 0 (read one, write the other)
     int hist_parity = 0;
