@@ -308,6 +308,13 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
         PG_HIP(hipMalloc((void **)&d_wide_taps, sizeof(float) * kMaxTaps));
         PG_HIP(hipMemcpy(d_wide_taps, wt.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
         kfirst = 2;
+        fused_front = first.cic3 != 0;
+        memset(&wide_fir, 0, sizeof(wide_fir));
+        wide_fir.ntaps = w.ntaps;
+        wide_fir.stride = (int)w.stride;
+        wide_fir.gain = 1.f;
+        for (int p = 0; p < w.ntaps; p++) wide_fir.h[p] = wt[p];
+        if (2 * (w.ntaps + 1) > kMaxTaps) fused_front = false;  // the mixed-pair history lives in a kMaxTaps-wide row
     }
     // the fused later stages
     memset(&casc, 0, sizeof(casc));
@@ -348,7 +355,7 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
     } else {
         if (halo0 > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "cascade look-back %lld too deep", halo0);
         if (wide) {
-            if (int rc = buf0.alloc((int)C, wide_taps - 1, len0)) return rc;
+            if (!fused_front) { if (int rc = buf0.alloc((int)C, wide_taps - 1, len0)) return rc; }
             if (int rc = buf1.alloc((int)C, (int)halo0, len0 / wide_stride)) return rc;
             if (int rc = fin.alloc((int)C, last_hist, len0 / wide_stride / later)) return rc;
         } else {
@@ -380,23 +387,37 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (n <= 0 || n % (long long)chain.total != 0)
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
-    if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-    // merged CIC3 over a shared stream: one workgroup mixes a group of channels from one fetch of the sample pairs
-    const int cg = (first.cic3 && first.stride > 2 && shared_input) ? 8 : 1;
-    size_t lds = mixdec_lds_bytes(first);
-    if (cg > 1 && lds < (size_t)cg * 258 * sizeof(float4)) lds = (size_t)cg * 258 * sizeof(float4);
-    launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), cdiv(C, cg)), dim3(256), lds, s, d_in, in_pitch, (int)shared_input, buf0.data(),
-               buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], (int)kMaxTaps, (const float *)osc.d_amp,
-               osc.a_inf, first, d_hist_mixed[hist_parity ^ 1], osc.inline_dyn, cg, (int)C);  // its last block leaves the next call's mixed history
-    hist_parity ^= 1;
-    if (after_first) PG_HIP(hipEventRecord(after_first, s));
-    len_out = len0;
     const HistBuf *src = &buf0;
-    if (wide) {  // the peeled stride->=8 stage: every output reads its own taps-long window straight from buf0
+    if (fused_front) {
         len1 = len0 / wide_stride;
-        launch(k_fir_dec, dim3(cdiv(len1, 256), C), dim3(256), s, (const float2 *)buf0.data(), buf0.pitch, buf1.data(), buf1.pitch, len1, wide_stride,
-               (const float *)d_wide_taps, (const float *)nullptr, 0, (const int *)nullptr, wide_taps, 1.0f, 0, (const int *)nullptr);
+        if (len1 > buf1.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+        const int cg = shared_input ? 8 : 1;
+        const int pitch = wide_stride * (kFrontOB - 1) + wide_taps + 1 + wide_stride;
+        launch_lds(k_mix_cic_hb, dim3(cdiv(len1, kFrontOB), cdiv(C, cg)), dim3(256), (size_t)cg * pitch * sizeof(float4), s, d_in, in_pitch, (int)shared_input,
+                   buf1.data(), buf1.pitch, len1, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1],
+                   (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, wide_fir, first.stride, 1.0f, osc.inline_dyn, cg, (int)C);
+        hist_parity ^= 1;
+        if (after_first) PG_HIP(hipEventRecord(after_first, s));
+        len_out = len1;
         src = &buf1;
+    } else {
+        if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+        // merged CIC3 over a shared stream: one workgroup mixes a group of channels from one fetch of the sample pairs
+        const int cg = (first.cic3 && first.stride > 2 && shared_input) ? 8 : 1;
+        size_t lds = mixdec_lds_bytes(first);
+        if (cg > 1 && lds < (size_t)cg * 258 * sizeof(float4)) lds = (size_t)cg * 258 * sizeof(float4);
+        launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), cdiv(C, cg)), dim3(256), lds, s, d_in, in_pitch, (int)shared_input, buf0.data(),
+                   buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], (int)kMaxTaps, (const float *)osc.d_amp,
+                   osc.a_inf, first, d_hist_mixed[hist_parity ^ 1], osc.inline_dyn, cg, (int)C);  // its last block leaves the next call's mixed history
+        hist_parity ^= 1;
+        if (after_first) PG_HIP(hipEventRecord(after_first, s));
+        len_out = len0;
+        if (wide) {  // the peeled stride->=8 stage: every output reads its own taps-long window straight from buf0
+            len1 = len0 / wide_stride;
+            launch(k_fir_dec, dim3(cdiv(len1, 256), C), dim3(256), s, (const float2 *)buf0.data(), buf0.pitch, buf1.data(), buf1.pitch, len1, wide_stride,
+                   (const float *)d_wide_taps, (const float *)nullptr, 0, (const int *)nullptr, wide_taps, 1.0f, 0, (const int *)nullptr);
+            src = &buf1;
+        }
     }
     if (casc.nst > 0) {
         len_out = n / (long long)chain.total;
@@ -408,7 +429,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
 }
 void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
-    if (buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
+    if (!fused_front && buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
     if (wide && buf1.hist > 0) jobs.push_back(TailJob{buf1.data(), buf1.pitch, len1, buf1.hist, 0, nullptr, 0});
     if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
 }

@@ -295,6 +295,104 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
     }
 }
 
+// Mixer + merged CIC3 (stride S0) + wide halfband (T1 taps, stride S1 >= 8) in one pass -- the front of every chain the
+// reference builds for narrow channels at >= 10 Msps and for WFM at >= 100 Msps (cic3 x S0, hb11 x 16, ...).  Output j of
+// the halfband reads CIC outputs S1 j - (T1-1) .. S1 j; CIC output k reads the sample pairs k-1 and k (pair P = samples
+// P S0, P S0 + 1): T1 + 1 pairs out of every S1.  Only those pairs are fetched and mixed, nothing at the CIC rate is
+// written -- the unfused route writes and re-reads 8 B per CIC output per channel, which is what a wide bank is bound by.
+//   tile: kFrontOB outputs x chan_group channels per workgroup; pairs S1 (j0 + jl) - T1 .. S1 (j0 + jl), jl < OB
+//   hist: [channel][2 (T1 + 1)] the previous call's last T1 + 1 mixed pairs (pairs -(T1+1) .. -1 of this call)
+// grid (ceil(n_out / kFrontOB), ceil(C / chan_group)), block 256; dynamic LDS = chan_group * npairs float4.
+constexpr int kFrontOB = 16;
+static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restrict__ in, long long in_pitch, int shared_input,
+                                                            float2 *__restrict__ out, long long out_pitch, long long n_out,
+                                                            const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
+                                                            float2 *__restrict__ hist_out, int hist_pitch, const float *__restrict__ amp_tab,
+                                                            float a_inf, FirTaps hb /* stage 1 */, int S0, float out_gain, OscDynInline dyn,
+                                                            int chan_group, int n_chan)
+{
+    HIP_DYNAMIC_SHARED(float4, pairs)
+    __shared__ float ht[kMaxTaps];
+    const int t = threadIdx.x;
+    const int T1 = hb.ntaps, S1 = hb.stride, NP = T1 + 1;
+    if (t < kMaxTaps) ht[t] = t < T1 ? hb.h[t] : 0.f;
+    const long long j0 = (long long)blockIdx.x * kFrontOB;
+    const int nout = (int)((n_out - j0) < kFrontOB ? (n_out - j0) : kFrontOB);
+    const long long P0 = (long long)S1 * j0 - T1;          // first pair of the tile
+    const int npairs = S1 * (nout - 1) + NP;               // pairs P0 .. S1 (j0 + nout - 1)
+    const bool last_tile = j0 + nout == n_out;
+    const int nload = last_tile ? npairs + (S1 - 1) : npairs;  // the last tile also mixes the pairs up to the end of the call: the next history
+    const int c0 = blockIdx.y * chan_group;
+    const int ng = (n_chan - c0) < chan_group ? (n_chan - c0) : chan_group;
+    const int lds_pitch = S1 * (kFrontOB - 1) + NP + S1;   // per channel of the group
+    for (int p = t; p < nload; p += 256) {
+        const long long P = P0 + p;
+        // pairs a halfband window never touches (S1 > T1 + 1) are skipped, except where they are the next call's history
+        const int u = (int)(((P % S1) + S1) % S1);
+        const bool used = u == 0 || u >= S1 - T1 || (last_tile && P >= (long long)S1 * n_out - NP);
+        if (!used) continue;
+        const long long i = P * (long long)S0;
+        float4 xx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= 0 && shared_input) xx = *reinterpret_cast<const float4 *>(in + i);
+        for (int g = 0; g < ng; g++) {
+            const int cg = c0 + g;
+            const ChanOsc *og = &osc[cg];
+            float2 a, b;
+            if (i < 0) {
+                const float2 *hp = hist + (long long)cg * hist_pitch + 2 * (NP + (int)P);  // P in [-(T1+1), -1]
+                a = hp[0];
+                b = hp[1];
+            } else {
+                if (!shared_input) xx = *reinterpret_cast<const float4 *>(in + (long long)cg * in_pitch + i);
+                a = make_float2(xx.x, xx.y);
+                b = make_float2(xx.z, xx.w);
+                if ((dyn.use ? dyn.d[cg].mix_on : og->mix_on) != 0) {
+                    const double gph0 = dyn.use ? dyn.d[cg].phase0 : og->phase0;
+                    const uint32_t gn0 = dyn.use ? dyn.d[cg].n0 : og->n0;
+                    const bool gset = gn0 >= (uint32_t)kAmpTab;
+                    const float2 ph = cis_cycles(gph0 + (double)(i + 1) * og->inc);
+                    const float2 ph1 = cmul(ph, og->step[1]);
+                    const float aa = gset ? a_inf : osc_amp(amp_tab, a_inf, gn0, i);
+                    const float ab = gset ? a_inf : osc_amp(amp_tab, a_inf, gn0, i + 1);
+                    a = cmul(cscale(ph, aa), a);
+                    b = cmul(cscale(ph1, ab), b);
+                }
+            }
+            pairs[g * lds_pitch + p] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    __syncthreads();
+    // the next call's history: the call's last T1 + 1 mixed pairs, written to the OTHER history buffer
+    if (last_tile && hist_out != nullptr) {
+        for (int w = t; w < ng * NP; w += 256) {
+            const int g = w / NP, q = w % NP;
+            const long long P = (long long)S1 * n_out - NP + q;
+            const float4 v = pairs[g * lds_pitch + (int)(P - P0)];
+            float2 *hp = hist_out + (long long)(c0 + g) * hist_pitch + 2 * q;
+            hp[0] = make_float2(v.x, v.y);
+            hp[1] = make_float2(v.z, v.w);
+        }
+    }
+    // one work-item per (output, channel of the group)
+    for (int w = t; w < nout * ng; w += 256) {
+        const int jl = w % nout, g = w / nout;
+        const float4 *pg = pairs + g * lds_pitch + S1 * jl;  // pair S1 (j0 + jl) - T1 + q at pg[q]
+        float2 acc = make_float2(0.f, 0.f);
+        float4 pv = pg[0];
+        for (int q = 1; q <= T1; q++) {
+            const float4 cu = pg[q];
+            // CIC3 output k = S1 (j0 + jl) - T1 + q from pairs k-1 (pv) and k (cu): .125 (od + pev + 3 (pod + ev))
+            const float cx = .125f * (cu.z + pv.x + 3.0f * (pv.z + cu.x));
+            const float cy = .125f * (cu.w + pv.y + 3.0f * (pv.w + cu.y));
+            const float h = ht[q - 1];
+            acc.x = fmaf(cx, h, acc.x);
+            acc.y = fmaf(cy, h, acc.y);
+            pv = cu;
+        }
+        out[(long long)(c0 + g) * out_pitch + j0 + jl] = cscale(acc, out_gain);
+    }
+}
+
 // Generic real-tap FIR on complex data with decimation: the CFir post-demod filters (stride 1) and any stand-alone
 // strided FIR.  `in` points at the data start; in[-(T-1)..-1] is history.
 //   y[c][o].re = gain * sum_p in[c][o*S + p - (T-1)].re * hI_c[p],   y.im likewise with hQ (CFir::ProcessFilter complex,

@@ -74,6 +74,8 @@ struct DecimCore {
     // A second stage with a stride >= 8 (merged halfbands at high input rates) would make the fused cascade's tiles mostly
     // halo: it runs as its own strided FIR (k_fir_dec) from buf0 into buf1, and the fused rest reads buf1.
     bool wide = false;
+    bool fused_front = false;        // merged CIC3 + wide halfband in one kernel (k_mix_cic_hb): nothing is written at the CIC rate
+    FirTaps wide_fir;                // the wide stage's taps as kernel arguments (fused_front)
     int wide_taps = 0, wide_stride = 1;
     float *d_wide_taps = nullptr;
     HistBuf buf1;
