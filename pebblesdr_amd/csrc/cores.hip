@@ -208,6 +208,12 @@ int OscBank::upload(hipStream_t s)
     PG_HIP(hipEventRecord(h_done[cur], s));
     return 0;
 }
+bool OscBank::any_transient() const
+{
+    for (const auto &c : ctl)
+        if (c.n0 < (uint64_t)kAmpTab) return true;
+    return false;
+}
 void OscBank::advance(uint64_t n)
 {
     for (auto &c : ctl) {
@@ -308,13 +314,10 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
         PG_HIP(hipMalloc((void **)&d_wide_taps, sizeof(float) * kMaxTaps));
         PG_HIP(hipMemcpy(d_wide_taps, wt.data(), sizeof(float) * kMaxTaps, hipMemcpyHostToDevice));
         kfirst = 2;
-        fused_front = first.cic3 != 0;
+        fused_front = first.cic3 != 0 && w.ntaps == kFrontT1;  // k_mix_cic_hb is built for the hb11 the ladder always picks here
         memset(&wide_fir, 0, sizeof(wide_fir));
-        wide_fir.ntaps = w.ntaps;
         wide_fir.stride = (int)w.stride;
-        wide_fir.gain = 1.f;
-        for (int p = 0; p < w.ntaps; p++) wide_fir.h[p] = wt[p];
-        if (2 * (w.ntaps + 1) > kMaxTaps) fused_front = false;  // the mixed-pair history lives in a kMaxTaps-wide row
+        for (int p = 0; p < w.ntaps && p < kFrontT1; p++) wide_fir.h[p] = wt[p];
     }
     // the fused later stages
     memset(&casc, 0, sizeof(casc));
@@ -391,11 +394,14 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (fused_front) {
         len1 = len0 / wide_stride;
         if (len1 > buf1.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-        const int cg = shared_input ? 8 : 1;
-        const int pitch = wide_stride * (kFrontOB - 1) + wide_taps + 1 + wide_stride;
-        launch_lds(k_mix_cic_hb, dim3(cdiv(len1, kFrontOB), cdiv(C, cg)), dim3(256), (size_t)cg * pitch * sizeof(float4), s, d_in, in_pitch, (int)shared_input,
-                   buf1.data(), buf1.pitch, len1, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1],
-                   (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, wide_fir, first.stride, 1.0f, osc.inline_dyn, cg, (int)C);
+        int cl_log2 = 0;
+        while ((1u << cl_log2) < C && cl_log2 < 6) cl_log2++;  // channels across the lanes of a wave; the other lanes take further outputs
+        const int R = 8;                                          // outputs per lane
+        const dim3 grid(cdiv(len1 + 1, 4LL * R * (64 >> cl_log2)), cdiv(C, 1u << cl_log2));
+        auto kern = osc.any_transient() ? k_mix_cic_hb<true> : k_mix_cic_hb<false>;
+        launch(kern, grid, dim3(256), s, d_in, in_pitch, (int)shared_input, buf1.data(), buf1.pitch, len1, (const ChanOsc *)osc.d_osc,
+               (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, wide_fir,
+               first.stride, 1.0f, osc.inline_dyn, cl_log2, (int)C, R);
         hist_parity ^= 1;
         if (after_first) PG_HIP(hipEventRecord(after_first, s));
         len_out = len1;

@@ -295,101 +295,109 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
     }
 }
 
-// Mixer + merged CIC3 (stride S0) + wide halfband (T1 taps, stride S1 >= 8) in one pass -- the front of every chain the
-// reference builds for narrow channels at >= 10 Msps and for WFM at >= 100 Msps (cic3 x S0, hb11 x 16, ...).  Output j of
+// Mixer + merged CIC3 (stride S0) + wide halfband (hb11, stride S1 >= 8) in one pass -- the front of every chain the
+// reference builds for narrow channels at >= 5 Msps and for WFM at >= 100 Msps (cic3 x S0, hb11 x 16, ...).  Output j of
 // the halfband reads CIC outputs S1 j - (T1-1) .. S1 j; CIC output k reads the sample pairs k-1 and k (pair P = samples
-// P S0, P S0 + 1): T1 + 1 pairs out of every S1.  Only those pairs are fetched and mixed, nothing at the CIC rate is
-// written -- the unfused route writes and re-reads 8 B per CIC output per channel, which is what a wide bank is bound by.
-//   tile: kFrontOB outputs x chan_group channels per workgroup; pairs S1 (j0 + jl) - T1 .. S1 (j0 + jl), jl < OB
-//   hist: [channel][2 (T1 + 1)] the previous call's last T1 + 1 mixed pairs (pairs -(T1+1) .. -1 of this call)
-// grid (ceil(n_out / kFrontOB), ceil(C / chan_group)), block 256; dynamic LDS = chan_group * npairs float4.
-constexpr int kFrontOB = 16;
+// P S0, P S0 + 1): a window of T1 + 1 pairs out of every S1.  Only those pairs are fetched and mixed, nothing at the CIC
+// rate is written -- the unfused route writes and re-reads 8 B per CIC output per channel, which is what a wide bank is
+// bound by.
+//   One work-item owns whole outputs of one channel: it fetches its window's 12 pairs (16-byte loads), mixes them with
+//   an oscillator phase it rotates pair to pair in registers, and runs the CIC3 + halfband arithmetic on the spot: no
+//   LDS, no barrier, so waves are limited by registers only.  Lanes of a wave are `CL` channels x 64/CL outputs; with a
+//   shared input stream all channels of an output load the same address (one line per load instruction).
+//   hist: [channel][2 (T1 + 1)] the previous call's last T1 + 1 mixed pairs (pairs -(T1+1) .. -1 of this call); one
+//   more "virtual output" per channel mixes the call's final T1 + 1 pairs into hist_out for the next call.
+// grid (ceil((n_out + 1) / (4 R 64/CL)), ceil(C / CL)), block 256 (four independent waves, R outputs per lane each).
+// TRANSIENT: some oscillator of the bank is inside its amplitude transient (the first kAmpTab samples after a reset):
+// per-sample amplitudes from the table; otherwise every amplitude is a_inf.  The host picks the variant per call.
+template <bool TRANSIENT>
 static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restrict__ in, long long in_pitch, int shared_input,
                                                             float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                             const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
                                                             float2 *__restrict__ hist_out, int hist_pitch, const float *__restrict__ amp_tab,
-                                                            float a_inf, FirTaps hb /* stage 1 */, int S0, float out_gain, OscDynInline dyn,
-                                                            int chan_group, int n_chan)
+                                                            float a_inf, FrontTaps hb /* stage 1: hb11 */, int S0, float out_gain, OscDynInline dyn,
+                                                            int cl_log2, int n_chan, int R)
 {
-    HIP_DYNAMIC_SHARED(float4, pairs)
-    __shared__ float ht[kMaxTaps];
-    const int t = threadIdx.x;
-    const int T1 = hb.ntaps, S1 = hb.stride, NP = T1 + 1;
-    if (t < kMaxTaps) ht[t] = t < T1 ? hb.h[t] : 0.f;
-    const long long j0 = (long long)blockIdx.x * kFrontOB;
-    const int nout = (int)((n_out - j0) < kFrontOB ? (n_out - j0) : kFrontOB);
-    const long long P0 = (long long)S1 * j0 - T1;          // first pair of the tile
-    const int npairs = S1 * (nout - 1) + NP;               // pairs P0 .. S1 (j0 + nout - 1)
-    const bool last_tile = j0 + nout == n_out;
-    const int nload = last_tile ? npairs + (S1 - 1) : npairs;  // the last tile also mixes the pairs up to the end of the call: the next history
-    const int c0 = blockIdx.y * chan_group;
-    const int ng = (n_chan - c0) < chan_group ? (n_chan - c0) : chan_group;
-    const int lds_pitch = S1 * (kFrontOB - 1) + NP + S1;   // per channel of the group
-    for (int p = t; p < nload; p += 256) {
-        const long long P = P0 + p;
-        // pairs a halfband window never touches (S1 > T1 + 1) are skipped, except where they are the next call's history
-        const int u = (int)(((P % S1) + S1) % S1);
-        const bool used = u == 0 || u >= S1 - T1 || (last_tile && P >= (long long)S1 * n_out - NP);
-        if (!used) continue;
-        const long long i = P * (long long)S0;
-        float4 xx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i >= 0 && shared_input) xx = *reinterpret_cast<const float4 *>(in + i);
-        for (int g = 0; g < ng; g++) {
-            const int cg = c0 + g;
-            const ChanOsc *og = &osc[cg];
-            float2 a, b;
-            if (i < 0) {
-                const float2 *hp = hist + (long long)cg * hist_pitch + 2 * (NP + (int)P);  // P in [-(T1+1), -1]
-                a = hp[0];
-                b = hp[1];
-            } else {
-                if (!shared_input) xx = *reinterpret_cast<const float4 *>(in + (long long)cg * in_pitch + i);
-                a = make_float2(xx.x, xx.y);
-                b = make_float2(xx.z, xx.w);
-                if ((dyn.use ? dyn.d[cg].mix_on : og->mix_on) != 0) {
-                    const double gph0 = dyn.use ? dyn.d[cg].phase0 : og->phase0;
-                    const uint32_t gn0 = dyn.use ? dyn.d[cg].n0 : og->n0;
-                    const bool gset = gn0 >= (uint32_t)kAmpTab;
-                    const float2 ph = cis_cycles(gph0 + (double)(i + 1) * og->inc);
-                    const float2 ph1 = cmul(ph, og->step[1]);
-                    const float aa = gset ? a_inf : osc_amp(amp_tab, a_inf, gn0, i);
-                    const float ab = gset ? a_inf : osc_amp(amp_tab, a_inf, gn0, i + 1);
-                    a = cmul(cscale(ph, aa), a);
-                    b = cmul(cscale(ph1, ab), b);
+    constexpr int T1 = kFrontT1, NP = T1 + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int CL = 1 << cl_log2, OL = 64 >> cl_log2;
+    const int c = blockIdx.y * CL + (lane & (CL - 1));
+    const int ol = lane >> cl_log2;
+    if (c >= n_chan) return;
+    const int S1 = hb.stride;
+    const ChanOsc *oc = &osc[c];
+    const double inc = oc->inc;
+    double phase0 = oc->phase0;
+    uint32_t n0 = oc->n0, mix_on = oc->mix_on;
+    if (dyn.use) {  // per-call oscillator state rides in the kernel arguments (scalar registers): select, don't index
+#pragma unroll
+        for (int k = 0; k < kOscInline; k++)
+            if (c == k) { phase0 = dyn.d[k].phase0; n0 = dyn.d[k].n0; mix_on = dyn.d[k].mix_on; }
+    }
+    const float2 step1 = oc->step[1];
+    const float2 rot = cis_cycles((double)S0 * inc);  // pair to pair
+    const float2 *in_c = shared_input ? in : in + (long long)c * in_pitch;
+    const float2 *hist_c = hist + (long long)c * hist_pitch;
+    // outputs 0 .. n_out-1, plus the virtual output n_out: the call's last NP pairs, mixed into hist_out for the next call
+    const long long n_work = hist_out != nullptr ? n_out + 1 : n_out;
+    const long long jb = ((long long)blockIdx.x * 4 + wv) * R * OL;
+    for (int r = 0; r < R; r++) {
+        const long long j = jb + (long long)r * OL + ol;
+        if (j >= n_work) break;
+        const bool virt = j == n_out;
+        const long long P0 = virt ? (long long)S1 * n_out - NP : (long long)S1 * j - T1;
+        float4 m[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) {  // all loads issued before any is consumed; pairs before the call's start are patched below
+            const long long P = P0 + q > 0 ? P0 + q : 0;
+            m[q] = *reinterpret_cast<const float4 *>(in_c + P * (long long)S0);
+        }
+        if (mix_on != 0) {
+            float2 ph = cis_cycles(phase0 + (double)(P0 * (long long)S0 + 1) * inc);
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                float aa = a_inf, ab = a_inf;
+                if (TRANSIENT) {
+                    const long long i = (P0 + q > 0 ? P0 + q : 0) * (long long)S0;
+                    aa = osc_amp(amp_tab, a_inf, n0, i);
+                    ab = osc_amp(amp_tab, a_inf, n0, i + 1);
+                }
+                const float2 a = cmul(cscale(ph, aa), make_float2(m[q].x, m[q].y));
+                const float2 b = cmul(cscale(cmul(step1, ph), ab), make_float2(m[q].z, m[q].w));
+                m[q] = make_float4(a.x, a.y, b.x, b.y);
+                ph = cmul(rot, ph);
+            }
+        }
+        if (P0 < 0) {  // the first output of a call: its leading pairs are the previous call's, already mixed
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                const int P = (int)P0 + q;
+                if (P < 0) {
+                    const float2 a = hist_c[2 * (NP + P)], b = hist_c[2 * (NP + P) + 1];
+                    m[q] = make_float4(a.x, a.y, b.x, b.y);
                 }
             }
-            pairs[g * lds_pitch + p] = make_float4(a.x, a.y, b.x, b.y);
         }
-    }
-    __syncthreads();
-    // the next call's history: the call's last T1 + 1 mixed pairs, written to the OTHER history buffer
-    if (last_tile && hist_out != nullptr) {
-        for (int w = t; w < ng * NP; w += 256) {
-            const int g = w / NP, q = w % NP;
-            const long long P = (long long)S1 * n_out - NP + q;
-            const float4 v = pairs[g * lds_pitch + (int)(P - P0)];
-            float2 *hp = hist_out + (long long)(c0 + g) * hist_pitch + 2 * q;
-            hp[0] = make_float2(v.x, v.y);
-            hp[1] = make_float2(v.z, v.w);
+        if (virt) {
+            float2 *hp = hist_out + (long long)c * hist_pitch;
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                hp[2 * q] = make_float2(m[q].x, m[q].y);
+                hp[2 * q + 1] = make_float2(m[q].z, m[q].w);
+            }
+            break;
         }
-    }
-    // one work-item per (output, channel of the group)
-    for (int w = t; w < nout * ng; w += 256) {
-        const int jl = w % nout, g = w / nout;
-        const float4 *pg = pairs + g * lds_pitch + S1 * jl;  // pair S1 (j0 + jl) - T1 + q at pg[q]
         float2 acc = make_float2(0.f, 0.f);
-        float4 pv = pg[0];
+#pragma unroll
         for (int q = 1; q <= T1; q++) {
-            const float4 cu = pg[q];
-            // CIC3 output k = S1 (j0 + jl) - T1 + q from pairs k-1 (pv) and k (cu): .125 (od + pev + 3 (pod + ev))
+            // CIC3 output k = S1 j - T1 + q from pairs k-1 and k: .125 (od + pev + 3 (pod + ev))
+            const float4 pv = m[q - 1], cu = m[q];
             const float cx = .125f * (cu.z + pv.x + 3.0f * (pv.z + cu.x));
             const float cy = .125f * (cu.w + pv.y + 3.0f * (pv.w + cu.y));
-            const float h = ht[q - 1];
-            acc.x = fmaf(cx, h, acc.x);
-            acc.y = fmaf(cy, h, acc.y);
-            pv = cu;
+            acc.x = fmaf(cx, hb.h[q - 1], acc.x);
+            acc.y = fmaf(cy, hb.h[q - 1], acc.y);
         }
-        out[(long long)(c0 + g) * out_pitch + j0 + jl] = cscale(acc, out_gain);
+        out[(long long)c * out_pitch + j] = cscale(acc, out_gain);
     }
 }
 

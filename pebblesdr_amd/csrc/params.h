@@ -27,6 +27,10 @@ struct FirTaps {
     float h[kMaxTaps];
 };
 
+// the wide hb11 stage behind a merged CIC3, as kernel arguments of k_mix_cic_hb
+constexpr int kFrontT1 = 11;
+struct FrontTaps { float h[kFrontT1]; int stride; };
+
 // later decimation stages fused in one kernel (k_cascade): taps live in the kernel-argument segment
 constexpr int kMaxCascade = 6;
 struct CascadeParams {

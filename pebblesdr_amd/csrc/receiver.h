@@ -61,6 +61,7 @@ struct OscBank {
     void retune(uint32_t ch, double f);           // Mixer::setFrequency, mixer.cpp:25-40
     int upload(hipStream_t s);                     // refresh the device blocks (async, from pinned staging)
     void advance(uint64_t n);                      // after a call consumed n samples
+    bool any_transient() const;                    // some oscillator is inside its amplitude transient (n0 < kAmpTab)
 };
 
 // ---- Mixer + Decimator ----
@@ -75,7 +76,7 @@ struct DecimCore {
     // halo: it runs as its own strided FIR (k_fir_dec) from buf0 into buf1, and the fused rest reads buf1.
     bool wide = false;
     bool fused_front = false;        // merged CIC3 + wide halfband in one kernel (k_mix_cic_hb): nothing is written at the CIC rate
-    FirTaps wide_fir;                // the wide stage's taps as kernel arguments (fused_front)
+    FrontTaps wide_fir;              // the wide stage's taps as kernel arguments (fused_front)
     int wide_taps = 0, wide_stride = 1;
     float *d_wide_taps = nullptr;
     HistBuf buf1;
