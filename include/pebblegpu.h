@@ -175,10 +175,20 @@ int pebblegpu_set_noise_filter(pebblegpu_receiver *rx, uint32_t channel, int on)
 /* S-meter: SignalStrength::fdEstimate (application/signalstrength.cpp:287-380; receiver.cpp:891-892, 959-960) on every
  * frame's unprocessed spectrum, per channel: float4 (peakDb, avgDb, snrDb, floorDb) at [channel * pitch + frame].  The
  * band window is the channel's band-pass (+-100 kHz in a WFM bank) around its mixer frequency.  avgDb is the value the
- * reference's squelch compares with m_squelchDb (receiver.cpp:893-897, 962-965); the gate itself stays with the host.
+ * reference's squelch compares with m_squelchDb (receiver.cpp:893-897, 962-965); see pebblegpu_set_squelch.
  * Needs spectrum_bins != 0.  The reference's 10-per-second update timer is forced open: every frame is measured. */
 int pebblegpu_receiver_enable_signal_strength(pebblegpu_receiver *rx, int on);
 const void *pebblegpu_receiver_signal_strength(const pebblegpu_receiver *rx, uint64_t *frames, uint64_t *pitch_frames);
+/* Squelch (Receiver::squelchChanged, receiver.cpp:704-707; the gate at :893-897 for WFM and :962-965 otherwise).  Once a
+ * super-frame has been mixed, decimated and (narrow chains) band-passed, avgDb of the most recent unprocessed spectrum
+ * is compared with squelch_db: below it the call ends there -- noise filter, AGC, demodulator and resampler are not run
+ * and keep their state, and the call reports zero audio samples (pebblegpu_receiver_audio's n, process_iq's n_audio),
+ * exactly the reference's early return.  -120 (DB::minDb, the reference's default) never closes the gate.  The decision
+ * costs one 16-byte read-back and a stream synchronisation per call, so it is made only while a threshold above -120
+ * is set.  Defined for the reference's own shape: a one-channel receiver called one super-frame at a time
+ * (PEBBLEGPU_E_UNSUPPORTED otherwise: a bank would need per-channel stream lengths behind the gate).  Turns the S-meter
+ * on; needs spectrum_bins != 0 and a spectrum in the same or an earlier call. */
+int pebblegpu_set_squelch(pebblegpu_receiver *rx, uint32_t channel, double squelch_db);
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);
 
 /* Host single-frame path with the reference's callback shape:

@@ -267,6 +267,7 @@ public:
     void demodModeChanged(DemodMode m) { if (h) status = report("set_demod_mode", pebblegpu_set_demod_mode(h, 0, (int)m)); } // receiver.cpp:640
     // agcModeChanged / agcThresholdChanged -> AGC::setAgcMode(mode, threshold) (agc.cpp:53-82)
     void agcModeChanged(int agcMode, int threshold) { if (h) status = report("set_agc", pebblegpu_set_agc(h, 0, agcMode, threshold)); }
+    void squelchChanged(double s) { if (h) status = report("set_squelch", pebblegpu_set_squelch(h, 0, s)); }                // receiver.cpp:704
     // bound as the device plugin's CB_ProcessIQData, like receiver.cpp:135-138
     void processIQData(CPX *in, uint16_t numSamples)
     {

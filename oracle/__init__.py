@@ -75,6 +75,7 @@ def lib():
         L.po_receiver_set_agc.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.po_receiver_set_conditioners.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.po_receiver_set_anf.argtypes = [C.c_void_p, C.c_int]
+        L.po_receiver_set_squelch.argtypes = [C.c_void_p, C.c_double]
         L.po_iq_balance.argtypes = [C.c_double, C.c_double, _dp, _dp, C.c_int]
         L.po_anf_init.argtypes = [C.c_void_p]
         L.po_anf_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
@@ -535,6 +536,10 @@ class Receiver:
 
     def set_anf(self, on=True):
         lib().po_receiver_set_anf(self.h, 1 if on else 0)
+
+    def set_squelch(self, squelch_db):
+        """Receiver::squelchChanged (receiver.cpp:704-707); -120 = never gate"""
+        lib().po_receiver_set_squelch(self.h, float(squelch_db))
 
     def set_audio_rate(self, rate):
         lib().po_receiver_set_audio_rate(self.h, int(rate))

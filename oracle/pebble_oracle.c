@@ -1053,6 +1053,7 @@ struct po_receiver {
     double *mixed, *working, *samplebuf, *bpout, *demodout;
     uint32_t samplebuf_len;
     int cond_flags; double iq_gain, iq_phase; po_iir dc; po_nb nb; po_anf anf; int anf_on;
+    double squelch_db, mixer_freq, bp_lo, bp_hi; double *last_spec; uint32_t spec_bins; /* squelch, receiver.cpp:704-707 */
     double *cond;            /* conditioned input frame */
     po_agc *agc;             /* receiver.cpp:264 AGC(m_demodSampleRate, m_demodFrames) */
     po_resampler *resamp;    /* receiver.cpp:184 */
@@ -1069,6 +1070,9 @@ po_receiver *po_receiver_new(uint32_t fs, uint32_t n, uint32_t spectrum_bins, ui
     r->dec_wfm = po_decimator_new();
     r->wfm_rate = (int)po_decimator_build(r->dec_wfm, fs, 200000, 0);    /* :212-213 */
     if (spectrum_bins) r->spec = po_spectrum_new(spectrum_bins, n, 0, 0); /* :221, signalspectrum.cpp:58 */
+    r->squelch_db = -120.0; /* DB::minDb, receiverwidget.cpp:82 */
+    r->spec_bins = spectrum_bins;
+    if (spectrum_bins) r->last_spec = (double *)calloc(spectrum_bins, sizeof(double));
     r->bp = po_fastfir_new(fastfir_fft ? fastfir_fft : 2048, fastfir_taps ? fastfir_taps : 1025); /* :261 */
     po_demod_am_init(&r->am, (double)r->demod_rate);                     /* :228, demod.cpp:62 */
     po_demod_sam_init(&r->sam, (double)r->demod_rate);                   /* demod.cpp:63 */
@@ -1096,15 +1100,16 @@ void po_receiver_free(po_receiver *r)
     po_decimator_free(r->dec); po_decimator_free(r->dec_wfm);
     po_spectrum_free(r->spec); po_fastfir_free(r->bp);
     free(r->mixed); free(r->working); free(r->samplebuf); free(r->bpout); free(r->demodout);
-    po_agc_free(r->agc); po_resampler_free(r->resamp); free(r->cond);
+    po_agc_free(r->agc); po_resampler_free(r->resamp); free(r->cond); free(r->last_spec);
     free(r);
 }
 
 void po_receiver_set_mode(po_receiver *r, int mode) { r->mode = mode; r->samplebuf_len = 0; } /* :640-655 */
-void po_receiver_set_mixer(po_receiver *r, double f) { po_mixer_set_frequency(&r->mixer, f); } /* :709-716 */
+void po_receiver_set_mixer(po_receiver *r, double f) { r->mixer_freq = f; po_mixer_set_frequency(&r->mixer, f); } /* :709-716 */
 int po_receiver_set_filter(po_receiver *r, double lo, double hi) /* :658-664, bandpassfilter.cpp:38-46 */
 {
     int rc = po_fastfir_setup(r->bp, (float)lo, (float)hi, 0, (double)(uint32_t)r->demod_rate);
+    r->bp_lo = lo; r->bp_hi = hi; /* BandPassFilter::lowFreq/highFreq */
     if (r->mode == PO_AM) po_demod_am_set_bandwidth(&r->am, hi - lo); /* demod.cpp:230-239 */
     return rc;
 }
@@ -1126,7 +1131,10 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
         in = r->cond;
     }
     /* :826 SignalSpectrum::unprocessed (timer gate forced open: every frame) */
-    if (r->spec && spectrum_db) po_spectrum_process(r->spec, in, n, spectrum_db);
+    if (r->spec && (spectrum_db || r->squelch_db > -120.0)) {
+        po_spectrum_process(r->spec, in, n, r->last_spec); /* SignalSpectrum::getUnprocessed: the latest frame's */
+        if (spectrum_db) memcpy(spectrum_db, r->last_spec, sizeof(double) * r->spec_bins);
+    }
     const double *next = in;
     if (po_mixer_process(&r->mixer, in, r->mixed, n)) next = r->mixed; /* :867 / :910 */
     int wfm = (r->mode == PO_FMM || r->mode == PO_FMS);
@@ -1141,6 +1149,9 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     if (r->samplebuf_len < r->n) return 0; /* :878-879 / :927-928 */
     uint32_t ns = r->n;
     r->samplebuf_len = 0;
+    if (wfm && r->squelch_db > -120.0 && r->last_spec) { /* :891-897 */
+        if (po_fd_estimate(r->last_spec, (int)r->spec_bins, r->fs, -100000, 100000, r->mixer_freq, NULL) < r->squelch_db) return 0;
+    }
     if (wfm) {
         /* :896 Demod::processBlock -> fmMono (stereo is out of scope: SURVEY 8(f) rank 4) */
         if (!r->audio_rate) { po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns); return ns; }
@@ -1157,6 +1168,9 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
      * bandpassfilter.cpp:53-56, which only works for the stock sizes). */
     int nb = po_fastfir_process(r->bp, (int)ns, r->samplebuf, r->bpout);
     if (nb <= 0) return 0;
+    if (r->squelch_db > -120.0 && r->last_spec) { /* :959-965: m_avgDb < m_squelchDb -> return, nothing behind it runs */
+        if (po_fd_estimate(r->last_spec, (int)r->spec_bins, r->fs, (float)r->bp_lo, (float)r->bp_hi, r->mixer_freq, NULL) < r->squelch_db) return 0;
+    }
     if (r->mode == PO_NONE) { memset(audio, 0, (size_t)nb * 2 * sizeof(double)); return (uint32_t)nb; } /* :968-971 */
     /* :974 NoiseFilter (ANF) */
     if (r->anf_on) po_anf_process(&r->anf, r->bpout, r->bpout, nb);
@@ -1180,5 +1194,6 @@ void po_receiver_set_conditioners(po_receiver *r, int flags, double gain_factor,
     r->cond_flags = flags; r->iq_gain = gain_factor; r->iq_phase = phase_factor;
 }
 void po_receiver_set_anf(po_receiver *r, int on) { r->anf_on = on; }
+void po_receiver_set_squelch(po_receiver *r, double squelch_db) { r->squelch_db = squelch_db; } /* :704-707 */
 void po_receiver_set_agc(po_receiver *r, int mode, int threshold) { po_agc_set_mode(r->agc, mode, threshold); }
 void po_receiver_set_audio_rate(po_receiver *r, uint32_t audio_rate) { r->audio_rate = audio_rate; }

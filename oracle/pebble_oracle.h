@@ -204,6 +204,7 @@ void po_receiver_set_audio_rate(po_receiver *r, uint32_t audio_rate);
  * in that order, before the spectrum and the mixer); anf: NoiseFilter on the narrow branch (receiver.cpp:974) */
 void po_receiver_set_conditioners(po_receiver *r, int flags, double gain_factor, double phase_factor);
 void po_receiver_set_anf(po_receiver *r, int on);
+void po_receiver_set_squelch(po_receiver *r, double squelch_db);       /* receiver.cpp:704-707; gate at :893-897, :962-965 */
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ SYMBOLS = [
     "pebblegpu_malloc", "pebblegpu_free", "pebblegpu_memcpy_h2d", "pebblegpu_memcpy_d2h", "pebblegpu_memset",
     "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps", "pebblegpu_normalize_iq",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
-    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter",
+    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
     "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
@@ -92,6 +92,7 @@ def _declare(L):
     L.pebblegpu_set_agc.argtypes = [vp, u32, i32, i32]
     L.pebblegpu_set_conditioners.argtypes = [vp, u32, i32, dbl, dbl]
     L.pebblegpu_set_noise_filter.argtypes = [vp, u32, i32]
+    L.pebblegpu_set_squelch.argtypes = [vp, u32, C.c_double]
     L.pebblegpu_receiver_process.argtypes = [vp, vp, u64]
     L.pebblegpu_receiver_audio.restype = vp
     L.pebblegpu_receiver_audio.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -293,6 +294,10 @@ class ReceiverBank:
 
     def set_noise_filter(self, ch, on=True):
         check(self.L, self.L.pebblegpu_set_noise_filter(self.h, ch, 1 if on else 0))
+
+    def set_squelch(self, ch, squelch_db):
+        """Receiver::squelchChanged: below squelch_db (avgDb of the latest spectrum) a call ends after the band-pass with no audio"""
+        check(self.L, self.L.pebblegpu_set_squelch(self.h, ch, float(squelch_db)))
 
     def set_agc(self, ch, agc_mode, threshold):
         check(self.L, self.L.pebblegpu_set_agc(self.h, ch, int(agc_mode), int(threshold)))

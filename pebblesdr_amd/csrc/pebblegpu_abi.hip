@@ -154,6 +154,11 @@ int pebblegpu_set_noise_filter(pebblegpu_receiver *h, uint32_t channel, int on)
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
     return h->rx.set_noise_filter(channel, on != 0);
 }
+int pebblegpu_set_squelch(pebblegpu_receiver *h, uint32_t channel, double squelch_db)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.set_squelch(channel, squelch_db);
+}
 int pebblegpu_set_demod_mode(pebblegpu_receiver *h, uint32_t channel, int mode)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");

@@ -281,6 +281,7 @@ public:
     int set_agc(uint32_t ch, int mode, int threshold);
     int set_conditioners(uint32_t stream, int flags, double iq_gain, double iq_phase);
     int set_noise_filter(uint32_t ch, bool on);
+    int set_squelch(uint32_t ch, double squelch_db);   // Receiver::squelchChanged, receiver.cpp:704-707
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();
@@ -302,6 +303,9 @@ public:
     SmBins *d_sm_bins = nullptr;
     long long smeter_pitch = 0;
     int enable_smeter(bool on);
+    double squelch_db_ = -120.0;      // DB::minDb: the gate never closes (receiverwidget.cpp:82)
+    float4 *h_gate_ = nullptr;        // pinned: the S-meter value the gate reads back
+    uint64_t squelched_calls = 0;
     bool profile_detail = false;      // record the per-kernel events too (pebblegpu_receiver_set_profiling)
     uint32_t audio_rate = 0;          // 0: audio stays at the demod rate (the resampRate == 1 branch, receiver.cpp:1000-1003)
     float2 *d_audio_rs = nullptr;     // [C][rs_pitch] resampled audio

@@ -87,6 +87,7 @@ Receiver::~Receiver()
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
     agc_.release(); resamp_.release(); cond_.release(); anf_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
+    if (h_gate_) (void)hipHostFree(h_gate_);
     if (d_smeter) (void)hipFree(d_smeter);
     if (d_sm_bins) (void)hipFree(d_sm_bins);
     audio.release();
@@ -132,6 +133,23 @@ int Receiver::enable_smeter(bool on)
         sm_dirty_ = true;
     }
     smeter_on = on;
+    return 0;
+}
+
+int Receiver::set_squelch(uint32_t ch, double squelch_db)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u of %u", ch, C);
+    if (squelch_db > -120.0) {
+        if (C != 1 || max_sf != 1)
+            return fail(PEBBLEGPU_E_UNSUPPORTED, "the squelch gate is defined for a one-channel receiver called one super-frame at a time");
+        if (int rc = enable_smeter(true)) return rc;
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    if (squelch_db > -120.0 && !h_gate_) {
+        PG_HIP(hipSetDevice(device));
+        PG_HIP(hipHostMalloc((void **)&h_gate_, sizeof(float4)));
+    }
+    squelch_db_ = squelch_db;
     return 0;
 }
 
@@ -278,6 +296,21 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (!wfm) {
         if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
         if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
+    }
+    // Squelch, receiver.cpp:893-897 / :962-965: below the threshold the reference returns here -- nothing behind the gate
+    // runs or changes state, and no audio leaves the call.
+    bool gate_closed = false;
+    if (squelch_db_ > -120.0) {
+        if (!last_spec_frames) return fail(PEBBLEGPU_E_INVALID, "the squelch gate needs a spectrum: none has been computed yet");
+        PG_HIP(hipMemcpyAsync(h_gate_, d_smeter + (last_spec_frames - 1), sizeof(float4), hipMemcpyDeviceToHost, stream_));
+        PG_HIP(hipStreamSynchronize(stream_));
+        gate_closed = (double)h_gate_->y < squelch_db_;  // m_avgDb < m_squelchDb
+    }
+    if (gate_closed) {
+        squelched_calls++;
+        last_audio_n = 0;
+        if (profile_detail) { if (wfm) PG_HIP(hipEventRecord(ev[4], stream_)); }
+    } else if (!wfm) {
         if (int rc = anf_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
         if (int rc = agc_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
@@ -288,17 +321,19 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
         if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
     }
-    last_audio_n = (uint64_t)nd;
-    if (audio_rate) {  // CFractResampler::Resample into the audio buffer, receiver.cpp:1000-1001
-        long long n_rs = 0;
-        if (int rc = resamp_.run(stream_, audio.data(), audio.pitch, nd, d_audio_rs, rs_pitch, &n_rs)) return rc;
-        last_audio_n = (uint64_t)n_rs;
+    if (!gate_closed) {
+        last_audio_n = (uint64_t)nd;
+        if (audio_rate) {  // CFractResampler::Resample into the audio buffer, receiver.cpp:1000-1001
+            long long n_rs = 0;
+            if (int rc = resamp_.run(stream_, audio.data(), audio.pitch, nd, d_audio_rs, rs_pitch, &n_rs)) return rc;
+            last_audio_n = (uint64_t)n_rs;
+        }
     }
     if (profile_detail) PG_HIP(hipEventRecord(ev[5], stream_));
     {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
-        if (wfm) wfmc_.tail_jobs(jobs);
+        if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
         if (int rc = run_save_tails(stream_, jobs, C)) return rc;
     }
     PG_HIP(hipEventRecord(ev[6], stream_));
@@ -329,8 +364,10 @@ int Receiver::process_iq(const double *iq, uint16_t n, double *audio_out, uint32
     float2 *dst = d_stage_in_ + acc_frames_ * nf;
     PG_HIP(hipMemcpy(dst, h_frame_.data(), sizeof(float2) * nf, hipMemcpyHostToDevice));
     *n_audio = 0;
-    if (spectrum_db && bins) {
+    if ((spectrum_db || squelch_db_ > -120.0) && bins) {  // the gate reads the latest frame's spectrum, wanted by the host or not
         if (int rc = process(dst, nf, true, false)) return rc;
+    }
+    if (spectrum_db && bins) {
         if (int rc = sync()) return rc;
         h_out_.resize(bins);
         PG_HIP(hipMemcpy(h_out_.data(), d_spec, sizeof(float) * bins, hipMemcpyDeviceToHost));

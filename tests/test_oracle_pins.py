@@ -358,3 +358,34 @@ def test_conditioner_restatements_closed_forms(oracle_mod):
     d = dc.process(np.full(2000000, 0.25 + 0.1j))
     assert abs(d[-1]) < 1e-3 and abs(d[0] - (0.25 + 0.1j)) < 1e-4
 
+
+
+def test_squelch_is_an_early_return_that_freezes_the_demodulator(oracle_mod):
+    """receiver.cpp:959-965: with avgDb of the latest spectrum under m_squelchDb the frame ends after the band-pass: no audio,
+    and the demodulator behind the gate keeps its state.  -120 (the default) never gates."""
+    fs, n, bins, fc = 2048000, 2048, 4096, 100e3
+    sf = 32 * 2048
+    t = np.arange(3 * sf) / fs
+    carrier = 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 700 * t)) * np.exp(2j * np.pi * fc * t)
+    rng = np.random.default_rng(3)
+    noise = 1e-5 * (rng.standard_normal(3 * sf) + 1j * rng.standard_normal(3 * sf))
+    x = carrier * np.repeat([1.0, 0.0, 1.0], sf) + noise
+
+    def run(squelch):
+        r = oracle_mod.Receiver(fs, n, bins)
+        r.set_mode(oracle_mod.AM); r.set_mixer(fc); r.set_filter(-5000, 5000); r.set_squelch(squelch)
+        return [r.process(x[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(3 * sf // n)]
+
+    gated, plain = run(-60.0), run(-120.0)
+    per_sf = sf // n
+    counts = [sum(len(a) for a in gated[k * per_sf:(k + 1) * per_sf]) for k in range(3)]
+    assert counts == [2048, 0, 2048]
+    assert [sum(len(a) for a in plain[k * per_sf:(k + 1) * per_sf]) for k in range(3)] == [2048, 2048, 2048]
+    first = np.concatenate(gated[:per_sf])
+    assert np.array_equal(first, np.concatenate(plain[:per_sf]))  # the gate changes nothing while it is open
+    # after the gate reopens the demodulator carries on from the state the first super-frame left (the ungated run's has
+    # meanwhile seen 2048 samples of silence, so the two differ), and the modulation is there
+    again, ungated = np.concatenate(gated[2 * per_sf:]).real, np.concatenate(plain[2 * per_sf:]).real
+    assert np.abs(again[1100:]).max() > 0.01
+    assert not np.allclose(again, ungated, rtol=0, atol=1e-6)
+    assert sum(len(a) for a in run(-10.0)) == 0  # a threshold above the carrier's average: every super-frame is gated

@@ -702,6 +702,79 @@ def test_signal_strength_per_frame(gpu_lib, oracle_mod):
         plain.enable_signal_strength(True)  # no spectrum to measure on
 
 
+def _gated_signal(fs, sf, fc, wfm, pattern, amp=0.1):
+    """one super-frame per entry of `pattern`: carrier present (1) or only the noise floor (0)"""
+    N = sf * len(pattern)
+    t = np.arange(N) / fs
+    env = np.repeat(np.asarray(pattern, dtype=np.float64), sf)
+    if wfm:
+        sig = amp * np.exp(1j * (2 * np.pi * fc * t + 5.0 * np.sin(2 * np.pi * 1000 * t)))
+    else:
+        sig = amp * (1 + 0.5 * np.cos(2 * np.pi * 700 * t)) * np.exp(2j * np.pi * fc * t)
+    return env * sig + lcg_noise(N, 9, 1e-5)
+
+
+@pytest.mark.parametrize("wfm", [False, True])
+def test_squelch_gate_is_the_reference_early_return(gpu_lib, oracle_mod, wfm):
+    """Squelch (receiver.cpp:704-707, gate at :893-897 / :962-965): a super-frame whose avgDb is under the threshold ends
+    after the band-pass -- no audio, and nothing behind the gate (AGC, demodulator, resampler) advances, so the audio after
+    the gate reopens continues from the state the last open super-frame left.  One channel, one super-frame per call."""
+    import pebblesdr_amd as P
+    fs, n, bins, fc = 2048000, 2048, 4096, 100e3
+    rx = P.ReceiverBank(fs, 1, True, wfm, bins, max_superframes=1, audio_rate=11025)
+    ref = oracle_mod.Receiver(fs, n, bins)
+    rx.set_mixer(0, fc); ref.set_mixer(fc)
+    if wfm:
+        ref.set_mode(oracle_mod.FMM)
+    else:
+        rx.set_mode(0, P.DM_AM); rx.set_bandpass(0, -5000, 5000); rx.set_agc(0, 1, 20)  # AGC_FAST
+        ref.set_mode(oracle_mod.AM); ref.set_filter(-5000, 5000); ref.set_agc(1, 20)
+    ref.set_audio_rate(11025)
+    rx.set_squelch(0, -60.0); ref.set_squelch(-60.0)
+    sf = rx.superframe
+    pattern = [1, 1, 0, 0, 1, 0, 1]
+    x = _gated_signal(fs, sf, fc, wfm, pattern)
+    for k, on in enumerate(pattern):
+        g = rx.process(x[k * sf:(k + 1) * sf])[0][0]
+        r = np.concatenate([ref.process(x[k * sf + f * n:k * sf + (f + 1) * n], want_spectrum=False)[0] for f in range(sf // n)])
+        assert len(g) == len(r), "super-frame %d" % k
+        assert (len(g) > 0) == bool(on)
+        if on:
+            assert rel_rms(g, r) <= (2e-5 if not wfm else TOL), "super-frame %d" % k
+    # -120 (DB::minDb) never gates: the silent super-frame is demodulated again
+    rx.set_squelch(0, -120.0); ref.set_squelch(-120.0)
+    g = rx.process(x[2 * sf:3 * sf])[0][0]
+    assert len(g) > 0
+    bank = P.ReceiverBank(fs, 2, True, False, bins, max_superframes=1)
+    with pytest.raises(P.PebbleGpuError):
+        bank.set_squelch(0, -60.0)  # defined for the reference's shape: one channel, one super-frame per call
+
+
+def test_squelch_on_the_single_frame_host_path(gpu_lib, oracle_mod):
+    """CB_ProcessIQData shape with a squelch set: the gate reads the latest frame's spectrum whether or not the host asked
+    for it, and a gated super-frame hands back zero audio samples."""
+    import pebblesdr_amd as P
+    fs, n, bins, fc = 2048000, 2048, 4096, -250e3
+    rx = P.ReceiverBank(fs, 1, True, False, bins, max_superframes=1)
+    ref = oracle_mod.Receiver(fs, n, bins)
+    rx.set_mode(0, P.DM_USB); rx.set_mixer(0, fc); rx.set_bandpass(0, 300, 3000); rx.set_squelch(0, -70.0)
+    ref.set_mode(oracle_mod.USB); ref.set_mixer(fc); ref.set_filter(300, 3000); ref.set_squelch(-70.0)
+    sf = rx.superframe
+    pattern = [1, 0, 1]
+    N = sf * len(pattern)
+    t = np.arange(N) / fs
+    x = np.repeat(np.asarray(pattern, dtype=np.float64), sf) * 0.05 * np.exp(2j * np.pi * (fc + 1500.0) * t) + lcg_noise(N, 5, 1e-5)
+    got, want = [], []
+    for f in range(N // n):
+        a, _ = rx.process_iq(x[f * n:(f + 1) * n], want_spectrum=False)
+        r, _ = ref.process(x[f * n:(f + 1) * n], want_spectrum=False)
+        assert len(a) == len(r), "frame %d" % f
+        got.append(a); want.append(r)
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert len(got) == 2 * 2048
+    assert rel_rms(got, want) <= TOL
+
+
 # ------------------------------------------------------------------------------------------------
 # SURVEY 8(f) row 3: DCRemoval, IQBalance, NoiseBlanker 1/2 ahead of the spectrum and the mixer; NoiseFilter (ANF)
 # ------------------------------------------------------------------------------------------------
