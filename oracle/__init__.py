@@ -378,7 +378,9 @@ class DemodSAM:
 
 class _WfmS(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fs", "d1_re", "d1_im", "deemph_alpha", "deemph_re", "deemph_im")] + \
-               [("mono_lp", _IirS), ("notch", _IirS), ("lp", _FirS)]
+               [("mono_lp", _IirS), ("notch", _IirS), ("lp", _FirS), ("hilbert", _FirS), ("pilot_bp", _IirS)] + \
+               [(n, C.c_double) for n in ("nco_phase", "nco_freq", "nco_lo", "nco_hi", "pll_alpha", "pll_beta", "err_ave", "err_alpha",
+                                          "phase_adjust")] + [("pilot_locked", C.c_int)]
 
 
 class DemodWFM:
@@ -397,6 +399,13 @@ class DemodWFM:
         out = np.empty_like(x)
         lib().po_demod_wfm_process_mono(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
         return out
+
+    def process_stereo(self, x):
+        """processDataStereo, audio part: -> (complex (left, right), pilot-lock flag of the block)"""
+        x = _c128(x)
+        out = np.empty_like(x)
+        locked = lib().po_demod_wfm_process_stereo(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
+        return out, bool(locked)
 
 
 def fd_estimate(spectrum_db, spectrum_rate, bp_lo, bp_hi, mixer_freq):

@@ -708,6 +708,115 @@ void po_demod_wfm_init(po_demod_wfm *d, double fs) /* init()+setSampleRate(), de
     po_fir_init_lp(&d->lp, 0, 1.0, 60.0, 15000.0, 1.4 * 15000.0, fs); /* :175 (m_OutRate == rate) */
     po_iir_init_br(&d->notch, 19000.0, 5, fs);                        /* :178 */
     d->deemph_alpha = (1.0 - exp(-1.0 / (fs * 75E-6)));               /* :181-183, 451-457 */
+    /* stereo members, setSampleRate :161-171 and initPilotPll :371-386 */
+    d->phase_adjust = -7.267e-6 * fs + 3.677;                         /* PHASE_ADJ_M, PHASE_ADJ_B (:60-61, :161) */
+    po_fir_init_const(&d->hilbert, fs);                               /* :167 InitConstFir(HILB_LENGTH, HILBLP_H) */
+    po_fir_generate_hb(&d->hilbert, 42000);                           /* :168 */
+    po_iir_init_bp(&d->pilot_bp, 19000.0, 500, fs);                   /* :171 */
+    const double norm = PO_TWOPI / fs;
+    d->nco_phase = 0.0;
+    d->nco_freq = -19000.0;                                           /* :374, as written: Hz, not yet normalised */
+    d->nco_lo = (d->nco_freq - 20.0) * norm;                          /* PILOTPLL_RANGE 20 */
+    d->nco_hi = (d->nco_freq + 20.0) * norm;
+    d->pll_alpha = 2.0 * .707 * 10.0 * norm;                          /* PILOTPLL_ZETA .707, PILOTPLL_BW 10 */
+    d->pll_beta = (d->pll_alpha * d->pll_alpha) / (4.0 * .707 * .707);
+    d->err_ave = 0.0;
+    d->err_alpha = (1.0 - exp(-1.0 / (fs * .5)));                     /* LOCK_TIMECONST .5 */
+}
+
+/* HILBLP_H, demod_wfm.cpp:79-98: 61-tap symmetric low-pass prototype (Kaiser-Bessel, 30 kHz at 250 kHz); first 31 taps */
+static const double po_hilb_half[31] = {
+    -0.000389631665953405, 0.000115430826670992, 0.000945331102222503, 0.001582460677684605,
+    0.001370803713784687, -0.000000000000000002, -0.002077413537668161, -0.003656132107176520,
+    -0.003372610825000167, -0.000649815020884706, 0.003583263233560064, 0.006997162933343487,
+    0.006990985399916562, 0.002383133886438500, -0.005324501734543406, -0.012092135317628615,
+    -0.013212201698221963, -0.006168904735839018, 0.007082277142635906, 0.020017841466263672,
+    0.024271835962039127, 0.014255112728911837, -0.008597071392140753, -0.034478282954624850,
+    -0.048147195828726633, -0.035409729589347565, 0.009623663461671806, 0.080084441681677138,
+    0.157278883310078170, 0.217148915611638180, 0.239688166538436750
+};
+void po_fir_init_const(po_fir *f, double fs) /* CFir::InitConstFir(NumTaps, pCoef, rate), fir.cpp:176-197 */
+{
+    memset(f, 0, sizeof(*f));
+    f->ntaps = 61;
+    f->fs = fs;
+    for (int i = 0; i < 61; i++) {
+        const double h = po_hilb_half[i <= 30 ? i : 60 - i];
+        f->coef[i] = h; f->coef[61 + i] = h;
+    }
+}
+
+/* Demod_WFM::arctan2, :792-821 -- the reference's own approximation, restated with its constants (2 pi where pi/2 would
+ * be the textbook value) because the pilot PLL's trajectory depends on it */
+static double po_wfm_arctan2(double y, double x)
+{
+    double angle;
+    if (x == 0.0) {
+        if (y > 0.0) return PO_TWOPI;
+        if (y == 0.0) return 0.0;
+        return -PO_TWOPI;
+    }
+    const double z = y / x;
+    if (fabs(z) < 1.0) {
+        angle = z / (1.0 + 0.2854 * z * z);
+        if (x < 0.0) {
+            if (y < 0.0) return angle - PO_PI;
+            return angle + PO_PI;
+        }
+    } else {
+        angle = PO_TWOPI - z / (z * z + 0.2854);
+        if (y < 0.0) return angle - PO_PI;
+    }
+    return angle;
+}
+
+int po_demod_wfm_process_stereo(po_demod_wfm *d, const double *in, double *out, int n) /* :255-297, 359-362 */
+{
+    double *raw = (double *)malloc((size_t)n * sizeof(double));
+    double *raw2 = (double *)calloc((size_t)n * 2 + 2, sizeof(double));
+    double *cpx = (double *)malloc((size_t)n * 2 * sizeof(double));
+    double *pil = (double *)malloc((size_t)n * 2 * sizeof(double));
+    double *phase = (double *)malloc((size_t)n * sizeof(double));
+    for (int i = 0; i < n; i++) { /* :258-263: no mono low-pass in front of the discriminator here */
+        double d0r = in[2 * i], d0i = in[2 * i + 1];
+        raw[i] = 0.25 * atan2((d->d1_re * d0i - d0r * d->d1_im), (d->d1_re * d0r + d->d1_im * d0i));
+        d->d1_re = d0r; d->d1_im = d0i;
+        raw2[2 * i] = raw[i]; raw2[2 * i + 1] = raw[i]; /* CFir real-in/complex-out puts the sample in both delay lines, fir.cpp:153-154 */
+    }
+    po_fir_process_cpx(&d->hilbert, n, raw2, cpx);      /* :268 */
+    po_iir_process_cpx(&d->pilot_bp, n, cpx, pil);      /* :271 */
+    for (int i = 0; i < n; i++) { /* processPilotPll, :392-429 */
+        const double sn = sin(d->nco_phase), cs = cos(d->nco_phase);
+        const double tr = cs * pil[2 * i] - sn * pil[2 * i + 1];
+        const double ti = cs * pil[2 * i + 1] + sn * pil[2 * i];
+        const double err = -po_wfm_arctan2(ti, tr);
+        d->nco_freq += (d->pll_beta * err);
+        if (d->nco_freq > d->nco_hi) d->nco_freq = d->nco_hi;
+        else if (d->nco_freq < d->nco_lo) d->nco_freq = d->nco_lo;
+        d->nco_phase += (d->nco_freq + d->pll_alpha * err);
+        phase[i] = d->nco_phase + d->phase_adjust;
+        d->err_ave = (1.0 - d->err_alpha) * d->err_ave + d->err_alpha * err * err;
+    }
+    d->nco_phase = fmod(d->nco_phase, PO_TWOPI);
+    d->pilot_locked = d->err_ave < 0.05; /* LOCK_MAG_THRESHOLD */
+    for (int i = 0; i < n; i++) { /* :272-293 */
+        if (d->pilot_locked) {
+            const double lmr = 2.0 * raw[i] * sin(phase[i] * 2.0);
+            out[2 * i] = raw[i] + lmr; out[2 * i + 1] = raw[i] - lmr;
+        } else {
+            out[2 * i] = raw[i]; out[2 * i + 1] = raw[i];
+        }
+    }
+    free(raw); free(raw2); free(cpx); free(pil); free(phase);
+    /* :359-361, shared with the mono path */
+    po_fir_process_cpx(&d->lp, n, out, out);
+    for (int i = 0; i < n; i++) {
+        d->deemph_re = (1.0 - d->deemph_alpha) * d->deemph_re + d->deemph_alpha * out[2 * i];
+        d->deemph_im = (1.0 - d->deemph_alpha) * d->deemph_im + d->deemph_alpha * out[2 * i + 1];
+        out[2 * i] = d->deemph_re * 2.0; out[2 * i + 1] = d->deemph_im * 2.0;
+    }
+    po_iir_process_cpx(&d->notch, n, out, out);
+    return d->pilot_locked;
 }
 void po_demod_wfm_process_mono(po_demod_wfm *d, const double *in, double *out, int n) /* :207-232 */
 {
@@ -1153,9 +1262,15 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
         if (po_fd_estimate(r->last_spec, (int)r->spec_bins, r->fs, -100000, 100000, r->mixer_freq, NULL) < r->squelch_db) return 0;
     }
     if (wfm) {
-        /* :896 Demod::processBlock -> fmMono (stereo is out of scope: SURVEY 8(f) rank 4) */
-        if (!r->audio_rate) { po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns); return ns; }
-        po_demod_wfm_process_mono(&r->wfm, r->samplebuf, r->demodout, (int)ns);
+        /* :896 Demod::processBlock */
+        /* demod.cpp:113-122: dmFMM -> fmMono, dmFMS -> fmStereo */
+        if (!r->audio_rate) {
+            if (r->mode == PO_FMS) po_demod_wfm_process_stereo(&r->wfm, r->samplebuf, audio, (int)ns);
+            else po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns);
+            return ns;
+        }
+        if (r->mode == PO_FMS) po_demod_wfm_process_stereo(&r->wfm, r->samplebuf, r->demodout, (int)ns);
+        else po_demod_wfm_process_mono(&r->wfm, r->samplebuf, r->demodout, (int)ns);
         /* :901, :1000-1001 resampRate = m_demodWfmSampleRate / m_audioOutRate */
         return (uint32_t)po_resampler_process(r->resamp, (int)ns, ((double)r->wfm_rate * 1.0) / ((double)r->audio_rate * 1.0), r->demodout, audio);
     }

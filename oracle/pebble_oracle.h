@@ -86,6 +86,7 @@ typedef struct {
     double icoef[2 * 75], qcoef[2 * 75]; /* m_ICoef / m_QCoef: what the complex ProcessFilter uses */
     double zre[75], zim[75];
 } po_fir;
+void po_fir_init_const(po_fir *f, double fs); /* the 61-tap Hilbert prototype, demod_wfm.cpp:79-98,167 */
 int po_fir_init_lp(po_fir *f, int ntaps, double scale, double astop, double fpass, double fstop, double fs);
 void po_fir_generate_hb(po_fir *f, double freq_offset);                  /* CFir::GenerateHBFilter, fir.cpp:454-468 */
 void po_fir_process_cpx(po_fir *f, int n, const double *in, double *out); /* in may == out */
@@ -124,19 +125,28 @@ typedef struct {
 void po_demod_sam_init(po_demod_sam *d, double fs);
 void po_demod_sam_process(po_demod_sam *d, const double *in, double *out, int n);
 
-/* ---- Demod_WFM::processDataMono: application/demod/demod_wfm.cpp:154-232, 451-485 ---- */
+/* ---- Demod_WFM::processDataMono / processDataStereo (audio; the RDS branch leaves the audio untouched and is not
+ * restated): application/demod/demod_wfm.cpp:154-232, 255-297, 359-362, 371-429, 451-485, 792-821 ---- */
 typedef struct {
     double fs, d1_re, d1_im, deemph_alpha, deemph_re, deemph_im;
     po_iir mono_lp, notch;
     po_fir lp;
+    /* stereo: Hilbert pair, pilot band-pass and pilot PLL (:161-171, :371-429) */
+    po_fir hilbert;
+    po_iir pilot_bp;
+    double nco_phase, nco_freq, nco_lo, nco_hi, pll_alpha, pll_beta, err_ave, err_alpha, phase_adjust;
+    int pilot_locked;
 } po_demod_wfm;
 void po_demod_wfm_init(po_demod_wfm *d, double fs);
+/* out = (left, right); returns the pilot-lock flag of this block (m_PilotLocked) */
+int po_demod_wfm_process_stereo(po_demod_wfm *d, const double *in, double *out, int n);
 /* in is const here; the reference overwrites its input (demod_wfm.cpp:212) */
 void po_demod_wfm_process_mono(po_demod_wfm *d, const double *in, double *out, int n);
 
 /* ---- Receiver::processIQData, DSP skeleton only: application/receiver.cpp:116-281, 758-1009 ----
  * Steps that are default-off / identity / GUI are omitted exactly as SURVEY.md 8(a-1) scopes them:
- * DCRemoval, IQBalance, NoiseBlanker, NoiseFilter, AGC, squelch (forced open), resampler, audio out. */
+ * DCRemoval, IQBalance, NoiseBlanker, NoiseFilter, AGC, squelch and resampler are default-off / identity until their
+ * setters below are used; audio out is the caller's. */
 /* ------------------------------------------------------------------------------------------------
  * AGC -- application/agc.{h,cpp}.  modes: 0 AGC_OFF, 1 ACG_FAST, 2 AGC_MED, 3 AGC_SLOW, 4 AGC_LONG
  * (agc.h enum AgcMode).  Parity unpinned: the reference holds no recorded values for this class.

@@ -389,3 +389,31 @@ def test_squelch_is_an_early_return_that_freezes_the_demodulator(oracle_mod):
     assert np.abs(again[1100:]).max() > 0.01
     assert not np.allclose(again, ungated, rtol=0, atol=1e-6)
     assert sum(len(a) for a in run(-10.0)) == 0  # a threshold above the carrier's average: every super-frame is gated
+
+
+def test_wfm_stereo_pilot_pll_of_the_reference_does_not_hold_lock(oracle_mod):
+    """Why FM-Stereo is not on the device path.  Restated line by line (processDataStereo,
+    demod_wfm.cpp:255-297; processPilotPll :392-429; arctan2 :792-821), the pilot PLL steers its NCO onto 19 kHz but its
+    phase detector -- Demod_WFM::arctan2 with 2*pi where the textbook approximation has pi/2 -- is discontinuous next to
+    the loop's operating point, so the loop ends in a limit cycle (|error| ~ 2.36 rad), the lock average climbs past
+    LOCK_MAG_THRESHOLD within the first blocks for every pilot phase, and from then on the block copies the mono signal to
+    both channels.  What the reference's dmFMS produces is therefore its mono discriminator output without the 75 kHz
+    pre-filter; there is no stereo separation to be bit-compatible with."""
+    fs = 256000.0
+    n, blocks = 2048, 24
+    t = np.arange(n * blocks) / fs
+    left, right = 0.9 * np.sin(2 * np.pi * 1000 * t), 0.9 * np.sin(2 * np.pi * 2500 * t)
+    for ph in (0.0, 1.0, 2.5, 3.67, 5.0):
+        mpx = 0.45 * (left + right) + 0.1 * np.sin(2 * np.pi * 19000 * t + ph) + 0.45 * (left - right) * np.sin(2 * (2 * np.pi * 19000 * t + ph))
+        x = 0.5 * np.exp(1j * 2 * np.pi * 75000 * np.cumsum(mpx) / fs)
+        d = oracle_mod.DemodWFM(fs)
+        locks, outs = [], []
+        for k in range(blocks):
+            o, lk = d.process_stereo(x[k * n:(k + 1) * n])
+            locks.append(lk)
+            outs.append(o)
+        assert not any(locks[3:]), "pilot phase %.2f" % ph
+        assert abs(d.s.nco_freq - (-19000.0 * 2 * np.pi / fs)) < 2e-6  # the frequency IS found ...
+        assert d.s.err_ave > 1.0                                        # ... the phase detector never settles
+        tail = np.concatenate(outs[8:])
+        assert np.array_equal(tail.real, tail.imag)                     # mono in both channels
