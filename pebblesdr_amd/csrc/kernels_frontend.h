@@ -308,9 +308,33 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
 //   hist: [channel][2 (T1 + 1)] the previous call's last T1 + 1 mixed pairs (pairs -(T1+1) .. -1 of this call); one
 //   more "virtual output" per channel mixes the call's final T1 + 1 pairs into hist_out for the next call.
 // grid (ceil((n_out + 1) / (4 R 64/CL)), ceil(C / CL)), block 256 (four independent waves, R outputs per lane each).
+// Row stores for the lanes-are-channels kernels below.  A lane finishing output j of channel c would store 8 bytes into
+// row c: 64 lanes = 64 different lines per store instruction, and the write path, not the arithmetic, set the pace
+// (33 M such stores took 0.25 ms).  Instead each wave parks its R x 64 results in a private LDS tile [output][channel]
+// (row pad 1: both the lane-wise writes and the transposed reads are conflict-free) and then writes whole row segments:
+// consecutive lanes = consecutive outputs of one channel, R*OL*8 bytes per channel (a full 128-byte line at R*OL = 16).
+__host__ __device__ inline int front_tile_slots(int cl_log2, int R) { return R * (64 >> cl_log2) * ((1 << cl_log2) + 1); }
+__device__ __forceinline__ void front_store_rows(const float2 *__restrict__ tile, float2 *__restrict__ out, long long out_pitch, long long n_out,
+                                                 int cbase, int n_chan, long long jb, int cl_log2, int R, int lane)
+{
+    const int CL = 1 << cl_log2, OL = 64 >> cl_log2;
+    const int per_chan = R * OL;                 // outputs of one channel in the wave's tile (a power of two)
+    const int pl = __ffs(per_chan) - 1;
+    wave_sync();
+    for (int it = 0; it < R; it++) {
+        const int idx = it * 64 + lane;
+        const int ch = idx >> pl, jt = idx & (per_chan - 1);
+        const long long j = jb + jt;
+        if (cbase + ch < n_chan && j < n_out) out[(long long)(cbase + ch) * out_pitch + j] = tile[jt * (CL + 1) + ch];
+    }
+}
+
 // TRANSIENT: some oscillator of the bank is inside its amplitude transient (the first kAmpTab samples after a reset):
 // per-sample amplitudes from the table; otherwise every amplitude is a_inf.  The host picks the variant per call.
-template <bool TRANSIENT>
+// UNIFORM: 64 channels across the lanes and one shared stream -- a wave's lanes then all read the same window, so its
+// address is wave-uniform and the loads go through the scalar cache (a vector load hands every lane its own copy: 16
+// cycles of L1 return path per 16-byte load whatever the addresses, which was ~40 % of this kernel's time).
+template <bool TRANSIENT, bool UNIFORM>
 static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restrict__ in, long long in_pitch, int shared_input,
                                                             float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                             const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
@@ -319,11 +343,16 @@ static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restr
                                                             int cl_log2, int n_chan, int R)
 {
     constexpr int T1 = kFrontT1, NP = T1 + 1;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    HIP_DYNAMIC_SHARED(float2, tiles)
+    if (UNIFORM) cl_log2 = 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = UNIFORM ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     const int CL = 1 << cl_log2, OL = 64 >> cl_log2;
-    const int c = blockIdx.y * CL + (lane & (CL - 1));
-    const int ol = lane >> cl_log2;
-    if (c >= n_chan) return;
+    const int cl = lane & (CL - 1), ol = lane >> cl_log2;
+    const int cbase = blockIdx.y * CL;
+    const bool live = cbase + cl < n_chan;       // idle lanes still help with the row stores
+    const int c = live ? cbase + cl : n_chan - 1;
+    float2 *tile = tiles + wv * front_tile_slots(cl_log2, R);
     const int S1 = hb.stride;
     const ChanOsc *oc = &osc[c];
     const double inc = oc->inc;
@@ -336,24 +365,40 @@ static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restr
     }
     const float2 step1 = oc->step[1];
     const float2 rot = cis_cycles((double)S0 * inc);  // pair to pair
-    const float2 *in_c = shared_input ? in : in + (long long)c * in_pitch;
+    const float2 *in_c = (UNIFORM || shared_input) ? in : in + (long long)c * in_pitch;
     const float2 *hist_c = hist + (long long)c * hist_pitch;
     // outputs 0 .. n_out-1, plus the virtual output n_out: the call's last NP pairs, mixed into hist_out for the next call
     const long long n_work = hist_out != nullptr ? n_out + 1 : n_out;
     const long long jb = ((long long)blockIdx.x * 4 + wv) * R * OL;
+    auto first_pair = [&](long long jj) { return jj == n_out ? (long long)S1 * n_out - NP : (long long)S1 * jj - T1; };
+    // all of a window's loads are issued together; pairs before the call's start are clamped here and patched from `hist`
+    auto load_window = [&](long long P0, float4 (&w)[NP]) {
+        if (P0 >= 0) {  // one 64-bit address, twelve 32-bit offsets
+            const float2 *p = in_c + P0 * (long long)S0;
+#pragma unroll
+            for (int q = 0; q < NP; q++) w[q] = *reinterpret_cast<const float4 *>(p + q * S0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                const long long P = P0 + q > 0 ? P0 + q : 0;
+                w[q] = *reinterpret_cast<const float4 *>(in_c + P * (long long)S0);
+            }
+        }
+    };
+    const float2 rot_out = cis_cycles((double)S0 * (double)(S1 * OL) * inc);  // this lane's output to its next one
+    float2 ph0 = make_float2(1.f, 0.f);
     for (int r = 0; r < R; r++) {
         const long long j = jb + (long long)r * OL + ol;
-        if (j >= n_work) break;
+        if (!live || j >= n_work) continue;
         const bool virt = j == n_out;
-        const long long P0 = virt ? (long long)S1 * n_out - NP : (long long)S1 * j - T1;
+        const long long P0 = first_pair(j);
         float4 m[NP];
-#pragma unroll
-        for (int q = 0; q < NP; q++) {  // all loads issued before any is consumed; pairs before the call's start are patched below
-            const long long P = P0 + q > 0 ? P0 + q : 0;
-            m[q] = *reinterpret_cast<const float4 *>(in_c + P * (long long)S0);
-        }
+        load_window(P0, m);
         if (mix_on != 0) {
-            float2 ph = cis_cycles(phase0 + (double)(P0 * (long long)S0 + 1) * inc);
+            // exact fp64 phase at the lane's first output, a constant rotation from one output to the next (the virtual
+            // window sits one pair off that grid: exact phase again)
+            ph0 = (r == 0 || virt) ? cis_cycles(phase0 + (double)(P0 * (long long)S0 + 1) * inc) : cmul(rot_out, ph0);
+            float2 ph = ph0;
 #pragma unroll
             for (int q = 0; q < NP; q++) {
                 float aa = a_inf, ab = a_inf;
@@ -385,7 +430,7 @@ static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restr
                 hp[2 * q] = make_float2(m[q].x, m[q].y);
                 hp[2 * q + 1] = make_float2(m[q].z, m[q].w);
             }
-            break;
+            continue;
         }
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
@@ -397,8 +442,135 @@ static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restr
             acc.x = fmaf(cx, hb.h[q - 1], acc.x);
             acc.y = fmaf(cy, hb.h[q - 1], acc.y);
         }
-        out[(long long)c * out_pitch + j] = cscale(acc, out_gain);
+        tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
     }
+    front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
+}
+
+// Mixer + first halfband stage (hb11, stride S) for a BANK of channels tuned off one shared stream -- the register form of
+// k_mix_dec1.  There a workgroup mixes one channel's tile into LDS: every channel re-reads the stream through L2 and
+// pays a load -> mix -> barrier -> FIR latency chain per 256 outputs, which is what a wide bank was bound by (0.29 ms
+// for 256 channels x 0.5 M samples, far off both the HBM and the VALU floor).  Here the lanes of a wave are 64 channels
+// of the bank and a work-item owns whole outputs of its channel: the window's six 16-byte loads are the same address in
+// every lane (one line per load instruction for 64 channels), the seven samples a halfband touches (even taps + centre)
+// are mixed with phases ph(i0) * step[d] from the channel's step table, the oscillator is rotated output to output in
+// registers (exact fp64 phase once per work-item), and the FIR is seven FMAs: no LDS, no barrier.
+//   y[o] = sum_p m[o S + p - 10] h[p]  (decimator.cpp:637-648), m = osc * x; m[i < 0] from `hist` ([channel][10] mixed)
+//   the virtual output o = n_out mixes the call's last ten samples into hist_out for the next call.
+// grid (ceil((n_out + 1) / (4 R 64/CL)), ceil(C / CL)), block 256 (four independent waves, R outputs per lane each).
+template <bool TRANSIENT, bool UNIFORM /* as in k_mix_cic_hb */>
+static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__restrict__ in, long long in_pitch, int shared_input,
+                                                               float2 *__restrict__ out, long long out_pitch, long long n_out,
+                                                               const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
+                                                               float2 *__restrict__ hist_out, int hist_pitch, const float *__restrict__ amp_tab,
+                                                               float a_inf, FrontTaps hb /* stage 0: hb11 */, float out_gain, OscDynInline dyn,
+                                                               int cl_log2, int n_chan, int R)
+{
+    constexpr int T = kFrontT1, H = T - 1;
+    HIP_DYNAMIC_SHARED(float2, tiles)
+    if (UNIFORM) cl_log2 = 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = UNIFORM ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
+    const int CL = 1 << cl_log2, OL = 64 >> cl_log2;
+    const int cl = lane & (CL - 1), ol = lane >> cl_log2;
+    const int cbase = blockIdx.y * CL;
+    const bool live = cbase + cl < n_chan;
+    const int c = live ? cbase + cl : n_chan - 1;
+    float2 *tile = tiles + wv * front_tile_slots(cl_log2, R);
+    const int S = hb.stride;
+    const ChanOsc *oc = &osc[c];
+    const double inc = oc->inc;
+    double phase0 = oc->phase0;
+    uint32_t n0 = oc->n0, mix_on = oc->mix_on;
+    if (dyn.use) {
+#pragma unroll
+        for (int k = 0; k < kOscInline; k++)
+            if (c == k) { phase0 = dyn.d[k].phase0; n0 = dyn.d[k].n0; mix_on = dyn.d[k].mix_on; }
+    }
+    // the window's used samples sit at offsets 0 2 4 5 6 8 10 from its first sample
+    const float2 st2 = oc->step[2], st4 = oc->step[4], st5 = oc->step[5], st6 = oc->step[6], st8 = oc->step[8], st10 = oc->step[10];
+    const float2 rot = cis_cycles((double)(S * OL) * inc);  // this lane's output to its next one
+    const float2 *in_c = (UNIFORM || shared_input) ? in : in + (long long)c * in_pitch;
+    const float2 *hist_c = hist + (long long)c * hist_pitch;
+    const long long n_work = hist_out != nullptr ? n_out + 1 : n_out;
+    const long long jb = ((long long)blockIdx.x * 4 + wv) * R * OL;
+    float2 ph = make_float2(1.f, 0.f);
+    // the six 16-byte loads of a window; pairs before the call's start are clamped here and patched from `hist` below
+    auto load_window = [&](long long jj, float4 (&w)[6]) {
+        const long long i0 = (long long)S * jj - H;
+        if (i0 >= 0) {  // one address, six immediate offsets
+            const float4 *p = reinterpret_cast<const float4 *>(in_c + i0);
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = p[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const long long i = i0 + 2 * k > 0 ? i0 + 2 * k : 0;
+                w[k] = *reinterpret_cast<const float4 *>(in_c + i);
+            }
+        }
+    };
+    for (int r = 0; r < R; r++) {
+        const long long j = jb + (long long)r * OL + ol;
+        if (!live || j >= n_work) continue;
+        if (j == n_out) {  // the next call's history: m[n - 10 .. n - 1], each with its exact phase
+            const long long n = n_out * S;
+            float2 *hp = hist_out + (long long)c * hist_pitch;
+#pragma unroll 1
+            for (int q = 0; q < H; q++) {
+                const long long i = n - H + q;
+                float2 v = in_c[i];
+                if (mix_on != 0) v = cmul(cscale(cis_cycles(phase0 + (double)(i + 1) * inc), osc_amp(amp_tab, a_inf, n0, i)), v);
+                hp[q] = v;
+            }
+            continue;
+        }
+        const long long i0 = (long long)S * j - H;  // even
+        float4 x[6];
+        load_window(j, x);
+        float2 m0 = make_float2(x[0].x, x[0].y), m2 = make_float2(x[1].x, x[1].y), m4 = make_float2(x[2].x, x[2].y), m5 = make_float2(x[2].z, x[2].w),
+               m6 = make_float2(x[3].x, x[3].y), m8 = make_float2(x[4].x, x[4].y), m10 = make_float2(x[5].x, x[5].y);
+        if (mix_on != 0) {
+            ph = r == 0 ? cis_cycles(phase0 + (double)(i0 + 1) * inc) : cmul(rot, ph);
+            if (TRANSIENT) {
+                auto amp = [&](int d) { const long long i = i0 + d; return osc_amp(amp_tab, a_inf, n0, i > 0 ? i : 0); };
+                m0 = cmul(cscale(ph, amp(0)), m0);
+                m2 = cmul(cscale(cmul(st2, ph), amp(2)), m2);
+                m4 = cmul(cscale(cmul(st4, ph), amp(4)), m4);
+                m5 = cmul(cscale(cmul(st5, ph), amp(5)), m5);
+                m6 = cmul(cscale(cmul(st6, ph), amp(6)), m6);
+                m8 = cmul(cscale(cmul(st8, ph), amp(8)), m8);
+                m10 = cmul(cscale(cmul(st10, ph), amp(10)), m10);
+            } else {
+                const float2 pa = cscale(ph, a_inf);
+                m0 = cmul(pa, m0);
+                m2 = cmul(cmul(st2, pa), m2);
+                m4 = cmul(cmul(st4, pa), m4);
+                m5 = cmul(cmul(st5, pa), m5);
+                m6 = cmul(cmul(st6, pa), m6);
+                m8 = cmul(cmul(st8, pa), m8);
+                m10 = cmul(cmul(st10, pa), m10);
+            }
+        }
+        if (i0 < 0) {  // output 0 of the call (S <= 10 would add output 1): its first ten samples are the previous call's
+            if (i0 + 0 < 0) m0 = hist_c[H + (int)i0 + 0];
+            if (i0 + 2 < 0) m2 = hist_c[H + (int)i0 + 2];
+            if (i0 + 4 < 0) m4 = hist_c[H + (int)i0 + 4];
+            if (i0 + 5 < 0) m5 = hist_c[H + (int)i0 + 5];
+            if (i0 + 6 < 0) m6 = hist_c[H + (int)i0 + 6];
+            if (i0 + 8 < 0) m8 = hist_c[H + (int)i0 + 8];
+            if (i0 + 10 < 0) m10 = hist_c[H + (int)i0 + 10];
+        }
+        float2 acc = cscale(m0, hb.h[0]);
+        acc.x = fmaf(m2.x, hb.h[2], acc.x);   acc.y = fmaf(m2.y, hb.h[2], acc.y);
+        acc.x = fmaf(m4.x, hb.h[4], acc.x);   acc.y = fmaf(m4.y, hb.h[4], acc.y);
+        acc.x = fmaf(m5.x, hb.h[5], acc.x);   acc.y = fmaf(m5.y, hb.h[5], acc.y);
+        acc.x = fmaf(m6.x, hb.h[6], acc.x);   acc.y = fmaf(m6.y, hb.h[6], acc.y);
+        acc.x = fmaf(m8.x, hb.h[8], acc.x);   acc.y = fmaf(m8.y, hb.h[8], acc.y);
+        acc.x = fmaf(m10.x, hb.h[10], acc.x); acc.y = fmaf(m10.y, hb.h[10], acc.y);
+        tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
+    }
+    front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
 }
 
 // Generic real-tap FIR on complex data with decimation: the CFir post-demod filters (stride 1) and any stand-alone

@@ -77,6 +77,8 @@ struct DecimCore {
     bool wide = false;
     bool fused_front = false;        // merged CIC3 + wide halfband in one kernel (k_mix_cic_hb): nothing is written at the CIC rate
     FrontTaps wide_fir;              // the wide stage's taps as kernel arguments (fused_front)
+    bool bank_front = false;         // hb11 first stage of a >= 16-channel bank: k_mix_hb11_bank when the input is shared
+    FrontTaps bank_taps;
     int wide_taps = 0, wide_stride = 1;
     float *d_wide_taps = nullptr;
     HistBuf buf1;
