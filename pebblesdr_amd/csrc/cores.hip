@@ -303,7 +303,7 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
     for (int p = 0; p < s0.ntaps; p++) first.h[p] = (float)design::halfband_taps(s0.design)[p];
     if (mixdec_lds_bytes(first) > 150 * 1024) return fail(PEBBLEGPU_E_UNSUPPORTED, "first-stage stride %u too wide for the LDS tile", s0.stride);
     // banks of >= 16 channels behind an hb11 first stage mix in registers when their input is one shared stream
-    bank_front = !first.cic3 && first.ntaps == kFrontT1 && C >= 16;
+    bank_front = !first.cic3 && first.ntaps == kFrontT1 && (C >= 16 || C == 1);
     memset(&bank_taps, 0, sizeof(bank_taps));
     bank_taps.stride = first.stride;
     for (int p = 0; p < kFrontT1 && p < first.ntaps; p++) bank_taps.h[p] = first.h[p];
@@ -405,7 +405,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         const dim3 grid(cdiv(len1 + 1, 4LL * R * (64 >> cl_log2)), cdiv(C, 1u << cl_log2));
         const bool uni = cl_log2 == 6 && shared_input;  // the lanes of a wave share one window: scalar loads
         auto kern = osc.any_transient() ? (uni ? k_mix_cic_hb<true, true> : k_mix_cic_hb<true, false>) : (uni ? k_mix_cic_hb<false, true> : k_mix_cic_hb<false, false>);
-        launch_lds(kern, grid, dim3(256), 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2), s, d_in, in_pitch, (int)shared_input, buf1.data(), buf1.pitch,
+        launch_lds(kern, grid, dim3(256), cl_log2 ? 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2) : 0, s, d_in, in_pitch, (int)shared_input, buf1.data(), buf1.pitch,
                    len1, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
                    (const float *)osc.d_amp, osc.a_inf, wide_fir, first.stride, 1.0f, osc.inline_dyn, cl_log2, (int)C, R);
         hist_parity ^= 1;
@@ -414,7 +414,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         src = &buf1;
     } else {
         if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-        if (bank_front && shared_input) {  // a bank off one shared stream: lanes = channels, windows in registers (k_mix_hb11_bank)
+        if (bank_front && (C >= 16 ? shared_input : want_lds_free)) {  // a bank off one shared stream: lanes = channels, windows in registers (k_mix_hb11_bank)
             int cl_log2 = 0;
             while ((1u << cl_log2) < C && cl_log2 < 6) cl_log2++;
             const int R = cl_log2 == 6 ? 16 : 8;
@@ -422,7 +422,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             const bool uni = cl_log2 == 6;
             auto kern = osc.any_transient() ? (uni ? k_mix_hb11_bank<true, true> : k_mix_hb11_bank<true, false>)
                                             : (uni ? k_mix_hb11_bank<false, true> : k_mix_hb11_bank<false, false>);
-            launch_lds(kern, grid, dim3(256), 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2), s, d_in, in_pitch, (int)shared_input, buf0.data(),
+            launch_lds(kern, grid, dim3(256), cl_log2 ? 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2) : 0, s, d_in, in_pitch, (int)shared_input, buf0.data(),
                        buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
                        (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, cl_log2, (int)C, R);
         } else {

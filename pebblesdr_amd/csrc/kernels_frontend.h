@@ -442,9 +442,10 @@ static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restr
             acc.x = fmaf(cx, hb.h[q - 1], acc.x);
             acc.y = fmaf(cy, hb.h[q - 1], acc.y);
         }
-        tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
+        if (cl_log2 == 0) out[(long long)c * out_pitch + j] = cscale(acc, out_gain);  // lanes = consecutive outputs of one channel
+        else tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
     }
-    front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
+    if (cl_log2 != 0) front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
 }
 
 // Mixer + first halfband stage (hb11, stride S) for a BANK of channels tuned off one shared stream -- the register form of
@@ -568,9 +569,10 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
         acc.x = fmaf(m6.x, hb.h[6], acc.x);   acc.y = fmaf(m6.y, hb.h[6], acc.y);
         acc.x = fmaf(m8.x, hb.h[8], acc.x);   acc.y = fmaf(m8.y, hb.h[8], acc.y);
         acc.x = fmaf(m10.x, hb.h[10], acc.x); acc.y = fmaf(m10.y, hb.h[10], acc.y);
-        tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
+        if (cl_log2 == 0) out[(long long)c * out_pitch + j] = cscale(acc, out_gain);  // lanes = consecutive outputs of one channel
+        else tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
     }
-    front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
+    if (cl_log2 != 0) front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
 }
 
 // Generic real-tap FIR on complex data with decimation: the CFir post-demod filters (stride 1) and any stand-alone

@@ -77,7 +77,9 @@ struct DecimCore {
     bool wide = false;
     bool fused_front = false;        // merged CIC3 + wide halfband in one kernel (k_mix_cic_hb): nothing is written at the CIC rate
     FrontTaps wide_fir;              // the wide stage's taps as kernel arguments (fused_front)
-    bool bank_front = false;         // hb11 first stage of a >= 16-channel bank: k_mix_hb11_bank when the input is shared
+    bool bank_front = false;         // hb11 first stage in registers (k_mix_hb11_bank): a >= 16-channel bank off a shared stream, or one channel when asked
+    bool want_lds_free = false;      // set per call by the owner: the first kernel should leave LDS alone (it runs beside the display transform)
+    bool front_is_lds_free() const { return C == 1 && (fused_front || bank_front); }
     FrontTaps bank_taps;
     int wide_taps = 0, wide_stride = 1;
     float *d_wide_taps = nullptr;
@@ -324,6 +326,11 @@ private:
     int apply_controls();
     std::mutex mu_;
     hipStream_t stream_ = nullptr;
+    // The display transform is arithmetic-bound and the front of the chain memory-bound: when the chain's first kernel
+    // needs no LDS (the register front ends) the two run side by side, the chain on its own stream between a fork and a
+    // join event.
+    hipStream_t chain_stream_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     std::vector<ChanCtl> ctl_;
     bool am_list_dirty_ = true, sm_dirty_ = true;
     long long pll_cap_ = 0;

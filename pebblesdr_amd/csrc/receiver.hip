@@ -29,6 +29,9 @@ int Receiver::create(const pebblegpu_config *cfg)
     if (nf < 256 || nf > 65535) return fail(PEBBLEGPU_E_INVALID, "frames_per_buffer must be 256..65535 (quint16, device_interfaces.h:32)");
     PG_HIP(hipSetDevice(device));
     PG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    PG_HIP(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
+    PG_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    PG_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     for (auto &row : tm.ev)
         for (auto &e : row) PG_HIP(hipEventCreate(&e));
 
@@ -95,6 +98,9 @@ Receiver::~Receiver()
     if (d_stage_in_) (void)hipFree(d_stage_in_);
     for (auto &row : tm.ev)
         for (auto &e : row) if (e) (void)hipEventDestroy(e);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (chain_stream_) (void)hipStreamDestroy(chain_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -265,6 +271,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
                     (unsigned long long)superframe);
     if (with_spectrum && (!bins || n % nf != 0 || n > (uint64_t)max_sf * superframe))
         return fail(PEBBLEGPU_E_SIZE, "spectrum needs whole frames of %u samples within capacity", nf);
+    // side by side: the chain goes to its own stream while the display transform keeps the arithmetic units busy (only when
+    // the chain's first kernel needs no LDS -- the transform's workgroups leave none -- and nothing downstream reads the
+    // spectrum or a conditioned copy of the input)
+    const bool side = with_spectrum && with_chain && !profile_detail && squelch_db_ <= -120.0 && dec_.front_is_lds_free() && !cond_.any && !cond_.dirty;
     if (int rc = apply_controls()) return rc;
     if (int rc = cond_.apply(stream_)) return rc;
     long long in_pitch = (long long)n;
@@ -273,6 +283,11 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     hipEvent_t *ev = tm.slot();
     tm.calls++;
     PG_HIP(hipEventRecord(ev[0], stream_));
+    hipStream_t cs = side ? chain_stream_ : stream_;
+    if (side) {
+        PG_HIP(hipEventRecord(ev_fork_, stream_));
+        PG_HIP(hipStreamWaitEvent(chain_stream_, ev_fork_, 0));
+    }
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
         if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
         last_spec_frames = n / nf;
@@ -289,52 +304,57 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         return 0;
     }
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
+    dec_.want_lds_free = side;
     // an event record costs the stream a ~5 us bubble: per-kernel events only when asked for (set_profiling)
-    if (int rc = dec_.run(stream_, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr)) return rc;
-    if (profile_detail) PG_HIP(hipEventRecord(ev[3], stream_));
+    if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr)) return rc;
+    if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
     const long long nd = dec_.out_len();
     if (!wfm) {
-        if (int rc = ff_.run(stream_, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
-        if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
+        if (int rc = ff_.run(cs, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
+        if (profile_detail) PG_HIP(hipEventRecord(ev[4], cs));
     }
     // Squelch, receiver.cpp:893-897 / :962-965: below the threshold the reference returns here -- nothing behind the gate
     // runs or changes state, and no audio leaves the call.
     bool gate_closed = false;
     if (squelch_db_ > -120.0) {
         if (!last_spec_frames) return fail(PEBBLEGPU_E_INVALID, "the squelch gate needs a spectrum: none has been computed yet");
-        PG_HIP(hipMemcpyAsync(h_gate_, d_smeter + (last_spec_frames - 1), sizeof(float4), hipMemcpyDeviceToHost, stream_));
-        PG_HIP(hipStreamSynchronize(stream_));
+        PG_HIP(hipMemcpyAsync(h_gate_, d_smeter + (last_spec_frames - 1), sizeof(float4), hipMemcpyDeviceToHost, cs));
+        PG_HIP(hipStreamSynchronize(cs));
         gate_closed = (double)h_gate_->y < squelch_db_;  // m_avgDb < m_squelchDb
     }
     if (gate_closed) {
         squelched_calls++;
         last_audio_n = 0;
-        if (profile_detail) { if (wfm) PG_HIP(hipEventRecord(ev[4], stream_)); }
+        if (profile_detail) { if (wfm) PG_HIP(hipEventRecord(ev[4], cs)); }
     } else if (!wfm) {
-        if (int rc = anf_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
-        if (int rc = agc_.run(stream_, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
+        if (int rc = anf_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
+        if (int rc = agc_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
-        if (int rc = am_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
-        if (sam_.C) { if (int rc = sam_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
-        if (nfm_.C) { if (int rc = nfm_.run(stream_, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
+        if (int rc = am_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
+        if (sam_.C) { if (int rc = sam_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
+        if (nfm_.C) { if (int rc = nfm_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
     } else {
-        if (profile_detail) PG_HIP(hipEventRecord(ev[4], stream_));
-        if (int rc = wfmc_.run(stream_, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
+        if (profile_detail) PG_HIP(hipEventRecord(ev[4], cs));
+        if (int rc = wfmc_.run(cs, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
     }
     if (!gate_closed) {
         last_audio_n = (uint64_t)nd;
         if (audio_rate) {  // CFractResampler::Resample into the audio buffer, receiver.cpp:1000-1001
             long long n_rs = 0;
-            if (int rc = resamp_.run(stream_, audio.data(), audio.pitch, nd, d_audio_rs, rs_pitch, &n_rs)) return rc;
+            if (int rc = resamp_.run(cs, audio.data(), audio.pitch, nd, d_audio_rs, rs_pitch, &n_rs)) return rc;
             last_audio_n = (uint64_t)n_rs;
         }
     }
-    if (profile_detail) PG_HIP(hipEventRecord(ev[5], stream_));
+    if (profile_detail) PG_HIP(hipEventRecord(ev[5], cs));
     {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
-        if (int rc = run_save_tails(stream_, jobs, C)) return rc;
+        if (int rc = run_save_tails(cs, jobs, C)) return rc;
+    }
+    if (side) {  // join: the call ends on the main stream once both pipelines have
+        PG_HIP(hipEventRecord(ev_join_, cs));
+        PG_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     }
     PG_HIP(hipEventRecord(ev[6], stream_));
     osc_.advance(n);
