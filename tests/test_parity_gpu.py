@@ -976,6 +976,93 @@ def test_full_size_configs3_512_channel_shard(gpu_lib, oracle_mod):
         assert rel_rms(g[c], want) <= TOL
 
 
+@pytest.mark.parametrize("C", [16, 37, 100])
+def test_register_first_stage_bank_sizes_and_retune(gpu_lib, oracle_mod, C):
+    """k_mix_hb11_bank (lanes = channels off one shared stream): channel counts that fill a wave, leave one ragged and span
+    two channel groups; three calls so the mixed-sample history and the oscillator's amplitude transient (first call only)
+    are both crossed, with one channel retuned between calls (Mixer::setFrequency resets the oscillator)."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    assert rx.chain()[0] == (11, 4)
+    fcs = [-950e3 + (1900e3 / C) * c for c in range(C)]
+    for c in range(C):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    check = sorted({0, 1, C // 2, C - 2, C - 1})
+    refs = {}
+    for c in check:
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fcs[c]); r.set_filter(300, 3000)
+        refs[c] = r
+    x = tones(fs, 3 * sf, [(0.02, fcs[c] + 900.0 + 11.0 * c) for c in check] + [(0.02, 123456.0 + 1500.0)]) + lcg_noise(3 * sf, 11, 1e-3)
+    for k in range(3):
+        if k == 2:  # retune the middle channel onto the extra tone
+            rx.set_mixer(C // 2, 123456.0); refs[C // 2].set_mixer(123456.0)
+        g = rx.process(x[k * sf:(k + 1) * sf])[0]
+        for c in check:
+            r = np.concatenate([refs[c].process(x[k * sf + f * n:k * sf + (f + 1) * n], want_spectrum=False)[0] for f in range(sf // n)])
+            assert g[c].shape == r.shape
+            assert rel_rms(g[c], r) <= TOL, "call %d channel %d" % (k, c)
+
+
+@pytest.mark.parametrize("fs,wfm", [(2048000, False), (20000000, True), (20000000, False)])
+def test_two_stream_call_equals_single_stream_call(gpu_lib, oracle_mod, fs, wfm):
+    """A one-channel call with a spectrum forks the chain onto a second stream (register first stage: hb11 at 2.048 Msps and
+    20 Msps WFM, CIC3 + hb11 at 20 Msps narrow); per-kernel profiling keeps the whole call on one stream with the LDS-tiled
+    first stage.  Both must give the oracle's audio and spectrum, call after call."""
+    import pebblesdr_amd as P
+    n, bins = 2048, 4096
+    fc = 0.11 * fs
+    a = P.ReceiverBank(fs, 1, True, wfm, bins, max_superframes=2)
+    b = P.ReceiverBank(fs, 1, True, wfm, bins, max_superframes=2)
+    b.set_profiling(True)
+    ref = oracle_mod.Receiver(fs, n, bins)
+    for rx in (a, b):
+        rx.set_mixer(0, fc)
+        if not wfm:
+            rx.set_mode(0, P.DM_AM); rx.set_bandpass(0, -5000, 5000)
+    ref.set_mixer(fc)
+    if wfm:
+        ref.set_mode(oracle_mod.FMM)
+    else:
+        ref.set_mode(oracle_mod.AM); ref.set_filter(-5000, 5000)
+    sf = a.superframe
+    # At D = 512 a 2048-sample reference frame feeds the late stages fewer samples than taps and the reference degrades to
+    # sample dropping (decimator.cpp:602-625; see test_config4_... for the frame size that avoids it): there the two paths
+    # are compared with each other only.
+    with_oracle = sf <= 200000
+    calls = [1, 2, 1] if with_oracle else [1, 1]
+    N = sum(calls) * sf
+    t = np.arange(N) / fs
+    if wfm:
+        x = 0.3 * np.exp(1j * (2 * np.pi * fc * t + 20.0 * np.sin(2 * np.pi * 1000 * t)))
+    else:
+        x = 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 700 * t)) * np.exp(2j * np.pi * fc * t)
+    x = x + lcg_noise(N, 13, 1e-3)
+    off = 0
+    for k in calls:
+        seg = x[off:off + k * sf]
+        ga, sa = a.process(seg)
+        gb, sb = b.process(seg)
+        assert ga[0].shape == gb[0].shape == (k * 2048,)
+        assert np.sqrt(np.mean(np.abs(gb[0]) ** 2)) > 1e-3
+        assert rel_rms(ga[0], gb[0]) <= 2e-6
+        assert np.abs(sa - sb).max() <= 1e-3
+        if with_oracle:
+            ra, rs = [], []
+            for f in range(len(seg) // n):
+                au, sp = ref.process(seg[f * n:(f + 1) * n])
+                ra.append(au); rs.append(sp)
+            ra = np.concatenate(ra)
+            assert ga[0].shape == ra.shape
+            assert rel_rms(ga[0], ra) <= TOL and rel_rms(gb[0], ra) <= TOL
+            first = 1 if off == 0 else 0  # frame 0 of a stream is undefined in the reference (uninitialised previous frame)
+            for f in range(first, len(rs), max(1, len(rs) // 7)):
+                assert db_err(sa[0, f], rs[f]) <= TOL_DB and db_err(sb[0, f], rs[f]) <= TOL_DB
+        off += k * sf
+
+
 def test_lifecycle_and_back_to_back_calls(gpu_lib, oracle_mod):
     """Create/destroy many banks (no leak large enough to fail an allocation), then 40 calls queued back to back without
     a host sync, with retunes, band changes and mode changes in between; the last super-frames must still match the
