@@ -976,6 +976,37 @@ def test_full_size_configs3_512_channel_shard(gpu_lib, oracle_mod):
         assert rel_rms(g[c], want) <= TOL
 
 
+@pytest.mark.parametrize("fs,C", [(1024000, 3), (2400000, 17), (3200000, 1), (5000000, 17), (8000000, 3), (10000000, 1), (10000000, 17),
+                                  (16000000, 3), (25000000, 17), (40000000, 1), (40000000, 3)])
+def test_chain_sweep_over_rates_and_bank_sizes(gpu_lib, oracle_mod, fs, C):
+    """Every first-stage form the ladder of decimator.cpp:74-146 produces between 1 and 40 Msps -- hb11 merged 2/4/8/16 times
+    (LDS-tiled for few channels, in registers for a bank, the stride-16 one peeled off the cascade) and CIC3 merged 1/2/3 times
+    in front of hb11 x 16 (the fused register front end) -- for one channel, a few and a ragged bank off one shared stream: USB
+    audio of the first and last channel against Mixer -> Decimator -> gain restore -> FastFIR restated by the oracle, two
+    calls.  The oracle is fed whole super-frames so that none of its stages sees fewer samples than taps."""
+    import pebblesdr_amd as P
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    chain = rx.chain()
+    rate = int(rx.info.demod_rate_int)
+    stages = sum(int(np.log2(st)) for _, st in chain)
+    fcs = [(-0.4 + 0.8 * (c + 0.5) / C) * fs for c in range(C)]
+    for c in range(C):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    x = tones(fs, 2 * sf, [(0.05, fc + 1000.0 + 50.0 * i) for i, fc in enumerate(fcs)]) + lcg_noise(2 * sf, 5, 1e-3)
+    g = np.concatenate([rx.process(x[:sf])[0], rx.process(x[sf:])[0]], axis=1)
+    for c in sorted({0, C - 1}):
+        mix = oracle_mod.Mixer(fs); mix.set_frequency(fcs[c])
+        dec = oracle_mod.Decimator(fs, 30000)
+        assert dec.chain() == chain
+        z = np.concatenate([dec.process(mix.process(x[:sf])), dec.process(mix.process(x[sf:]))]) * 10 ** (2 * stages / 20.0)
+        ff = oracle_mod.FastFIR(); ff.setup(300, 3000, 0, rate)
+        r = np.concatenate([ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048)])
+        assert r.shape == g[c].shape
+        for k in range(2):
+            assert rel_rms(g[c][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL, "channel %d call %d chain %s" % (c, k, chain)
+
+
 @pytest.mark.parametrize("C", [16, 37, 100])
 def test_register_first_stage_bank_sizes_and_retune(gpu_lib, oracle_mod, C):
     """k_mix_hb11_bank (lanes = channels off one shared stream): channel counts that fill a wave, leave one ragged and span
