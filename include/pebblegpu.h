@@ -148,6 +148,12 @@ int pebblegpu_set_agc(pebblegpu_receiver *rx, uint32_t channel, int agc_mode, in
  *            set, the resampled audio instead: the count pebblegpu_receiver_audio reports (same for all channels)
  *   spectrum [stream][n_samples / frames_per_buffer][bins] float, dB amplitude, -f..+f (fft.cpp:395) */
 int pebblegpu_receiver_process(pebblegpu_receiver *rx, const void *d_iq, uint64_t n_samples);
+/* The same call fed with the device's own sample format (what ProducerConsumer hands normalizeIQ,
+ * deviceinterfacebase.cpp:648-838): d_raw holds n_streams x n_samples raw IQ pairs, stream-major, in `format`
+ * (pebblegpu_iq_format) and `iq_order`; they are scaled by the format's constant and `gain` into a library-owned float2
+ * buffer on the library's stream (no host synchronisation) and processed as above.  Moves 2-4 bytes per sample over
+ * PCIe/HBM on the way in instead of 8. */
+int pebblegpu_receiver_process_raw(pebblegpu_receiver *rx, int format, int iq_order, double gain, const void *d_raw, uint64_t n_samples);
 /* returns channel 0's row; channel c starts *pitch_samples float2 further per channel */
 const void *pebblegpu_receiver_audio(const pebblegpu_receiver *rx, uint64_t *samples_per_channel, uint64_t *pitch_samples);
 const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *frames_per_stream);

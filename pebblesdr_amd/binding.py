@@ -15,7 +15,7 @@ SYMBOLS = [
     "pebblegpu_malloc", "pebblegpu_free", "pebblegpu_memcpy_h2d", "pebblegpu_memcpy_d2h", "pebblegpu_memset",
     "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps", "pebblegpu_normalize_iq",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
-    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch",
+    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch", "pebblegpu_receiver_process_raw",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
     "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
@@ -94,6 +94,7 @@ def _declare(L):
     L.pebblegpu_set_noise_filter.argtypes = [vp, u32, i32]
     L.pebblegpu_set_squelch.argtypes = [vp, u32, C.c_double]
     L.pebblegpu_receiver_process.argtypes = [vp, vp, u64]
+    L.pebblegpu_receiver_process_raw.argtypes = [vp, i32, i32, C.c_double, vp, u64]
     L.pebblegpu_receiver_audio.restype = vp
     L.pebblegpu_receiver_audio.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.pebblegpu_receiver_spectrum.restype = vp
@@ -304,6 +305,10 @@ class ReceiverBank:
 
     def process_device(self, dptr, n_samples):
         check(self.L, self.L.pebblegpu_receiver_process(self.h, C.c_void_p(dptr), int(n_samples)))
+
+    def process_raw_device(self, dptr, n_samples, fmt, iq_order=0, gain=1.0):
+        """raw device-format IQ pairs (pebblegpu_iq_format) already on the device -> normalizeIQ + the full call"""
+        check(self.L, self.L.pebblegpu_receiver_process_raw(self.h, int(fmt), int(iq_order), float(gain), C.c_void_p(dptr), int(n_samples)))
 
     def synchronize(self):
         check(self.L, self.L.pebblegpu_receiver_synchronize(self.h))

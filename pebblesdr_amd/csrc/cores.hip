@@ -225,7 +225,7 @@ void OscBank::advance(uint64_t n)
     }
 }
 
-int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst)
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait)
 {
     double scale = gain;
     if (fmt == 0 || fmt == 1) scale *= 1 / 128.0;        // deviceinterfacebase.cpp:651,689
@@ -233,9 +233,9 @@ int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long lo
     else if (fmt == 4) scale *= 1 / 32767.0;             // wavfile.cpp:299-300
     long long blocks = (n + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    launch(k_normalize_iq, dim3((unsigned)blocks), dim3(256), (hipStream_t) nullptr, d_src, d_dst, n, fmt, order, (float)scale);
+    launch(k_normalize_iq, dim3((unsigned)blocks), dim3(256), s, d_src, d_dst, n, fmt, order, (float)scale);
     PG_HIP(hipGetLastError());
-    PG_HIP(hipStreamSynchronize(nullptr));
+    if (wait) PG_HIP(hipStreamSynchronize(s));
     return 0;
 }
 

@@ -10,7 +10,6 @@ struct pebblegpu_receiver {
 using pg::fail;
 namespace pg {
 int probe_copy(int lane_bytes, size_t bytes, int iters, float *gbps);
-int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst);
 }
 
 extern "C" {
@@ -84,7 +83,7 @@ int pebblegpu_normalize_iq(int device, int format, int iq_order, double gain, co
     if (!d_src || !d_dst || format < 0 || format > PEBBLEGPU_IQ_WAV16 || iq_order < 0 || iq_order > 3 || n_samples == 0)
         return fail(PEBBLEGPU_E_INVALID, "bad argument");
     if (int rc = need_device(device)) return rc;
-    return pg::run_normalize_iq(format, iq_order, gain, d_src, (long long)n_samples, (float2 *)d_dst);
+    return pg::run_normalize_iq(format, iq_order, gain, d_src, (long long)n_samples, (float2 *)d_dst, nullptr, true);
 }
 
 int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out)
@@ -169,6 +168,11 @@ int pebblegpu_receiver_process(pebblegpu_receiver *h, const void *d_iq, uint64_t
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
     return h->rx.process((const float2 *)d_iq, n_samples, h->rx.bins != 0, true);
+}
+int pebblegpu_receiver_process_raw(pebblegpu_receiver *h, int format, int iq_order, double gain, const void *d_raw, uint64_t n_samples)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.process_raw(format, iq_order, gain, d_raw, n_samples);
 }
 const void *pebblegpu_receiver_audio(const pebblegpu_receiver *h, uint64_t *samples_per_channel, uint64_t *pitch_samples)
 {

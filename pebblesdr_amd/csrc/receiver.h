@@ -37,6 +37,7 @@ int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait);
 int run_signal_strength(hipStream_t s, const float *d_spec, long long stream_pitch, int bins, long long n_frames, const SmBins *d_bins,
                         float4 *d_out, long long out_pitch, uint32_t channels);
 
@@ -285,6 +286,7 @@ public:
     int set_agc(uint32_t ch, int mode, int threshold);
     int set_conditioners(uint32_t stream, int flags, double iq_gain, double iq_phase);
     int set_noise_filter(uint32_t ch, bool on);
+    int process_raw(int fmt, int order, double gain, const void *d_raw, uint64_t n);  // normalizeIQ on the library's stream, then process()
     int set_squelch(uint32_t ch, double squelch_db);   // Receiver::squelchChanged, receiver.cpp:704-707
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
@@ -346,6 +348,7 @@ private:
     ResampCore resamp_;
     SpectrumCore spec_;
     float2 *d_stage_in_ = nullptr;
+    float2 *d_raw_stage_ = nullptr;   // process_raw: the normalised copy of a raw device-format call (allocated on first use)
     std::vector<float> h_frame_, h_out_;
     uint64_t acc_frames_ = 0;
 };

@@ -91,6 +91,7 @@ Receiver::~Receiver()
     agc_.release(); resamp_.release(); cond_.release(); anf_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
     if (h_gate_) (void)hipHostFree(h_gate_);
+    if (d_raw_stage_) (void)hipFree(d_raw_stage_);
     if (d_smeter) (void)hipFree(d_smeter);
     if (d_sm_bins) (void)hipFree(d_sm_bins);
     audio.release();
@@ -359,6 +360,21 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     PG_HIP(hipEventRecord(ev[6], stream_));
     osc_.advance(n);
     return 0;
+}
+
+int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, uint64_t n)
+{
+    if (!d_raw || n == 0) return fail(PEBBLEGPU_E_INVALID, "null input or zero samples");
+    if (fmt < 0 || fmt > 4 || order < 0 || order > 3) return fail(PEBBLEGPU_E_INVALID, "unknown sample format %d / IQ order %d", fmt, order);
+    if (n > (uint64_t)max_sf * superframe) return fail(PEBBLEGPU_E_SIZE, "%llu samples exceed this object's capacity", (unsigned long long)n);
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        PG_HIP(hipSetDevice(device));
+        if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
+        // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
+        if (int rc = run_normalize_iq(fmt, order, gain, d_raw, (long long)(S * n), d_raw_stage_, stream_, false)) return rc;
+    }
+    return process(d_raw_stage_, n, bins != 0, true);
 }
 
 int Receiver::sync()

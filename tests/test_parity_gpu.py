@@ -512,6 +512,42 @@ def _streambank_refs(oracle_mod, fs, bands, N):
     return refs
 
 
+def test_process_raw_equals_normalize_then_process(gpu_lib, oracle_mod):
+    """pebblegpu_receiver_process_raw: HackRF-shape int8 pairs (and int16 in Q,I order for two independent streams) go through
+    normalizeIQ on the library's stream and then the ordinary call; the audio and spectrum must be those of process() fed
+    the same samples converted on the host with the reference's constants (deviceinterfacebase.cpp:651, :729)."""
+    import pebblesdr_amd as P
+    fs, bins = 2048000, 4096
+    rng = np.random.default_rng(7)
+    for fmt, dtype, scale, order, S in ((0, np.int8, 128.0, 0, 1), (2, np.int16, 32768.0, 1, 2)):
+        a = P.ReceiverBank(fs, S, S == 1, True, bins, max_superframes=2)
+        b = P.ReceiverBank(fs, S, S == 1, True, bins, max_superframes=2)
+        for rx in (a, b):
+            for c in range(S):
+                rx.set_mixer(c, 150e3)
+        n = 2 * a.superframe
+        t = np.arange(n) / fs
+        amp = 0.4 * scale
+        sig = np.stack([amp * np.exp(1j * (2 * np.pi * 150e3 * t + (10.0 + 5 * k) * np.sin(2 * np.pi * 1000 * t))) for k in range(S)])
+        raw = np.empty((S, n, 2), dtype=dtype)
+        raw[..., 0] = np.round(sig.real + rng.uniform(-1, 1, sig.shape)).astype(dtype)
+        raw[..., 1] = np.round(sig.imag + rng.uniform(-1, 1, sig.shape)).astype(dtype)
+        first, second = (raw[..., 0], raw[..., 1]) if order == 0 else (raw[..., 1], raw[..., 0])  # IQ or QI on the wire
+        x = (first.astype(np.float32) * np.float32(0.5 / scale) + 1j * (second.astype(np.float32) * np.float32(0.5 / scale))).astype(np.complex64)
+        buf = P.DeviceBuffer.from_array(raw, 0)
+        try:
+            a.process_raw_device(buf.ptr, n, fmt, order, 0.5)
+            ga, sa = a.audio(), a.spectrum()
+        finally:
+            buf.free()
+        gb, sb = b.process(x)
+        assert ga.shape == gb.shape and np.abs(ga).max() > 1e-3
+        assert np.array_equal(ga, gb)
+        assert np.array_equal(sa, sb)
+    with pytest.raises(P.PebbleGpuError):
+        a.process_raw_device(1, n, 9)  # unknown format
+
+
 def test_config5_streambank_small(gpu_lib, oracle_mod):
     """3 streams x 3 calls x 2 frames of 65536: every stream has its own filter; the band-pass overlap and the
     spectrum's previous-frame average carry across calls (fastfir.cpp:312-316, fft.cpp:349-353)."""
