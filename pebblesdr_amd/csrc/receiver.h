@@ -332,7 +332,10 @@ private:
     // needs no LDS (the register front ends) the two run side by side, the chain on its own stream between a fork and a
     // join event.
     hipStream_t chain_stream_ = nullptr;
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    // No events of its own: the chain stream waits for the call's start event, the call's end event is recorded on the chain
+    // stream once it has also seen the transform's end event, and whatever next touches the main stream (the next call, a
+    // synchronise) first waits for that end event.  Every event record costs the stream ~5 us, so none is spent on the fork/join.
+    hipEvent_t chain_end_ = nullptr;  // the end event of a two-stream call the main stream has not waited for yet
     std::vector<ChanCtl> ctl_;
     bool am_list_dirty_ = true, sm_dirty_ = true;
     long long pll_cap_ = 0;

@@ -30,8 +30,6 @@ int Receiver::create(const pebblegpu_config *cfg)
     PG_HIP(hipSetDevice(device));
     PG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     PG_HIP(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
-    PG_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-    PG_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     for (auto &row : tm.ev)
         for (auto &e : row) PG_HIP(hipEventCreate(&e));
 
@@ -86,6 +84,7 @@ int Receiver::create(const pebblegpu_config *cfg)
 Receiver::~Receiver()
 {
     (void)hipSetDevice(device);
+    if (chain_stream_) (void)hipStreamSynchronize(chain_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
     agc_.release(); resamp_.release(); cond_.release(); anf_.release();
@@ -99,8 +98,6 @@ Receiver::~Receiver()
     if (d_stage_in_) (void)hipFree(d_stage_in_);
     for (auto &row : tm.ev)
         for (auto &e : row) if (e) (void)hipEventDestroy(e);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (chain_stream_) (void)hipStreamDestroy(chain_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -276,6 +273,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // the chain's first kernel needs no LDS -- the transform's workgroups leave none -- and nothing downstream reads the
     // spectrum or a conditioned copy of the input)
     const bool side = with_spectrum && with_chain && !profile_detail && squelch_db_ <= -120.0 && dec_.front_is_lds_free() && !cond_.any && !cond_.dirty;
+    if (chain_end_) {  // the previous call's chain may still be running on its own stream
+        PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
+        chain_end_ = nullptr;
+    }
     if (int rc = apply_controls()) return rc;
     if (int rc = cond_.apply(stream_)) return rc;
     long long in_pitch = (long long)n;
@@ -286,8 +287,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     PG_HIP(hipEventRecord(ev[0], stream_));
     hipStream_t cs = side ? chain_stream_ : stream_;
     if (side) {
-        PG_HIP(hipEventRecord(ev_fork_, stream_));
-        PG_HIP(hipStreamWaitEvent(chain_stream_, ev_fork_, 0));
+        PG_HIP(hipStreamWaitEvent(chain_stream_, ev[0], 0));  // fork: the input is ready where the call's start event is
     }
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
         if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
@@ -353,11 +353,13 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
         if (int rc = run_save_tails(cs, jobs, C)) return rc;
     }
-    if (side) {  // join: the call ends on the main stream once both pipelines have
-        PG_HIP(hipEventRecord(ev_join_, cs));
-        PG_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+    if (side) {  // join: the call has ended once both pipelines have; the main stream catches up with it at its next use
+        PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+        PG_HIP(hipEventRecord(ev[6], cs));
+        chain_end_ = ev[6];
+    } else {
+        PG_HIP(hipEventRecord(ev[6], stream_));
     }
-    PG_HIP(hipEventRecord(ev[6], stream_));
     osc_.advance(n);
     return 0;
 }
@@ -370,6 +372,10 @@ int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, ui
     {
         std::lock_guard<std::mutex> g(mu_);
         PG_HIP(hipSetDevice(device));
+        if (chain_end_) {  // the previous call's chain may still be reading the staging buffer
+            PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
+            chain_end_ = nullptr;
+        }
         if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
         // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
         if (int rc = run_normalize_iq(fmt, order, gain, d_raw, (long long)(S * n), d_raw_stage_, stream_, false)) return rc;
@@ -381,6 +387,7 @@ int Receiver::sync()
 {
     PG_HIP(hipSetDevice(device));
     PG_HIP(hipStreamSynchronize(stream_));
+    PG_HIP(hipStreamSynchronize(chain_stream_));
     return 0;
 }
 
