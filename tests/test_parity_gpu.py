@@ -1043,6 +1043,40 @@ def test_chain_sweep_over_rates_and_bank_sizes(gpu_lib, oracle_mod, fs, C):
             assert rel_rms(g[c][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL, "channel %d call %d chain %s" % (c, k, chain)
 
 
+@pytest.mark.parametrize("fs", [2400000, 5000000, 25000000])
+@pytest.mark.parametrize("mode", ["AM", "NFM", "CWU"])
+def test_demod_modes_at_the_other_demod_rates(gpu_lib, oracle_mod, fs, mode):
+    """The narrow demodulators away from 64 kHz: 37 500, 39 062 and 48 828 Hz (the integer-truncated rates of receiver.h:165)
+    behind three different chains.  Oracle: Mixer -> Decimator -> gain restore -> FastFIR -> demodulator on whole
+    super-frames.  NFM is compared once its PLL has acquired (see the NFM note in DESIGN.md section 3)."""
+    import pebblesdr_amd as P
+    rx = P.ReceiverBank(fs, 1, True, False, 0, max_superframes=1)
+    rate = int(rx.info.demod_rate_int)
+    stages = sum(int(np.log2(st)) for _, st in rx.chain())
+    fc = 0.17 * fs
+    lo, hi = {"AM": (-5000, 5000), "NFM": (-4000, 4000), "CWU": (-1000, -500)}[mode]
+    rx.set_mode(0, {"AM": P.DM_AM, "NFM": P.DM_FMN, "CWU": P.DM_CWU}[mode]); rx.set_mixer(0, fc); rx.set_bandpass(0, lo, hi)
+    sf = rx.superframe
+    t = np.arange(3 * sf) / fs
+    if mode == "AM":
+        x = 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 700 * t)) * np.exp(2j * np.pi * fc * t)
+    elif mode == "NFM":
+        x = 0.1 * np.exp(1j * (2 * np.pi * fc * t + 2.0 * np.sin(2 * np.pi * 800 * t)))
+    else:
+        x = 0.1 * np.exp(2j * np.pi * (fc + (lo + hi) / 2) * t)
+    x = x + lcg_noise(3 * sf, 5, 1e-4)
+    g = np.concatenate([rx.process(x[k * sf:(k + 1) * sf])[0] for k in range(3)], axis=1)[0]
+    mix = oracle_mod.Mixer(fs); mix.set_frequency(fc)
+    dec = oracle_mod.Decimator(fs, 30000)
+    z = np.concatenate([dec.process(mix.process(x[k * sf:(k + 1) * sf])) for k in range(3)]) * 10 ** (2 * stages / 20.0)
+    ff = oracle_mod.FastFIR(); ff.setup(lo, hi, 0, rate)
+    dm = oracle_mod.DemodAM(rate, hi - lo) if mode == "AM" else oracle_mod.DemodNFM(rate) if mode == "NFM" else None
+    r = np.concatenate([(dm.process(y) if dm else y) for y in (ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048))])
+    assert r.shape == g.shape
+    for k in range(1 if mode == "NFM" else 0, 3):
+        assert rel_rms(g[k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= (TOL if mode != "NFM" else 2e-5), "frame %d" % k
+
+
 @pytest.mark.parametrize("C", [16, 37, 100])
 def test_register_first_stage_bank_sizes_and_retune(gpu_lib, oracle_mod, C):
     """k_mix_hb11_bank (lanes = channels off one shared stream): channel counts that fill a wave, leave one ragged and span
