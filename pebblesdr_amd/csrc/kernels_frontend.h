@@ -252,19 +252,23 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
     const float2 *x = in + (long long)c * in_pitch + first;
     float2 *src = buf, *dst = buf + cp.lds_half;
     // all of this tile's loads in flight together (as in k_mix_dec1): batches of kBatch, issued before any LDS store
+    // (16-byte lanes: `first`, the row pitch and cnt[0] are all even, so the tile is a whole number of aligned sample pairs)
     {
-        constexpr int kBatch = 6;
-        for (int jb = t; jb < cnt[0]; jb += 256 * kBatch) {
-            float2 v[kBatch];
+        constexpr int kBatch = 5;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        float4 *s4 = reinterpret_cast<float4 *>(src);
+        const int n4 = cnt[0] >> 1;
+        for (int jb = t; jb < n4; jb += 256 * kBatch) {
+            float4 v[kBatch];
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 const int j = jb + 256 * k;
-                v[k] = j < cnt[0] ? x[j] : make_float2(0.f, 0.f);
+                v[k] = j < n4 ? x4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 const int j = jb + 256 * k;
-                if (j < cnt[0]) src[j] = v[k];
+                if (j < n4) s4[j] = v[k];
             }
         }
     }
