@@ -414,7 +414,18 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         src = &buf1;
     } else {
         if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
-        if (bank_front && (C >= 16 ? shared_input : want_lds_free)) {  // a bank off one shared stream: lanes = channels, windows in registers (k_mix_hb11_bank)
+        if (bank_front && C == 1 && want_lds_free && !osc.any_transient()) {
+            // beside the spectrum kernel: the lean one-channel kernel for every output inside the call, and the general one
+            // (a handful of lanes) for the first outputs, whose windows reach back into the mixed history, and the new history
+            const int R = 8;
+            const long long j_first = (10 + first.stride - 1) / first.stride;
+            launch(k_mix_hb11_lean, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc, osc.a_inf, bank_taps,
+                   first.gain, osc.inline_dyn, R, j_first);
+            launch(k_mix_hb11_bank<false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch, (int)shared_input, buf0.data(), buf0.pitch,
+                   len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
+                   (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first);
+        } else if (bank_front && (C >= 16 ? shared_input : want_lds_free)) {
+ // a bank off one shared stream: lanes = channels, windows in registers (k_mix_hb11_bank)
             int cl_log2 = 0;
             while ((1u << cl_log2) < C && cl_log2 < 6) cl_log2++;
             const int R = cl_log2 == 6 ? 16 : 8;
@@ -424,7 +435,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
                                             : (uni ? k_mix_hb11_bank<false, true> : k_mix_hb11_bank<false, false>);
             launch_lds(kern, grid, dim3(256), cl_log2 ? 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2) : 0, s, d_in, in_pitch, (int)shared_input, buf0.data(),
                        buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
-                       (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, cl_log2, (int)C, R);
+                       (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, cl_log2, (int)C, R, -1LL);
         } else {
         // merged CIC3 over a shared stream: one workgroup mixes a group of channels from one fetch of the sample pairs
         const int cg = (first.cic3 && first.stride > 2 && shared_input) ? 8 : 1;

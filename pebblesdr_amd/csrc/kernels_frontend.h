@@ -469,7 +469,8 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
                                                                const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
                                                                float2 *__restrict__ hist_out, int hist_pitch, const float *__restrict__ amp_tab,
                                                                float a_inf, FrontTaps hb /* stage 0: hb11 */, float out_gain, OscDynInline dyn,
-                                                               int cl_log2, int n_chan, int R)
+                                                               int cl_log2, int n_chan, int R,
+                                                               long long edges_below /* >= 0: only outputs j < edges_below and the history */)
 {
     constexpr int T = kFrontT1, H = T - 1;
     HIP_DYNAMIC_SHARED(float2, tiles)
@@ -498,7 +499,9 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
     const float2 *in_c = (UNIFORM || shared_input) ? in : in + (long long)c * in_pitch;
     const float2 *hist_c = hist + (long long)c * hist_pitch;
     const long long n_work = hist_out != nullptr ? n_out + 1 : n_out;
-    const long long jb = ((long long)blockIdx.x * 4 + wv) * R * OL;
+    // edges only: a two-block launch, block 0 for the first outputs and the block that holds output n_out for the history
+    const long long bx = edges_below >= 0 && blockIdx.x != 0 ? n_out / (4LL * R * OL) : (long long)blockIdx.x;
+    const long long jb = (bx * 4 + wv) * R * OL;
     float2 ph = make_float2(1.f, 0.f);
     // the six 16-byte loads of a window; pairs before the call's start are clamped here and patched from `hist` below
     auto load_window = [&](long long jj, float4 (&w)[6]) {
@@ -518,6 +521,7 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
     for (int r = 0; r < R; r++) {
         const long long j = jb + (long long)r * OL + ol;
         if (!live || j >= n_work) continue;
+        if (edges_below >= 0 && j >= edges_below && j != n_out) continue;  // the rest comes from k_mix_hb11_lean
         if (j == n_out) {  // the next call's history: m[n - 10 .. n - 1], each with its exact phase
             const long long n = n_out * S;
             float2 *hp = hist_out + (long long)c * hist_pitch;
@@ -577,6 +581,55 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
         else tile[(r * OL + ol) * (CL + 1) + cl] = cscale(acc, out_gain);
     }
     if (cl_log2 != 0) front_store_rows(tile, out, out_pitch, n_out, cbase, n_chan, jb, cl_log2, R, lane);
+}
+
+// The one-channel form of the above that runs BESIDE the spectrum kernel (receiver.hip, two-stream call).  That kernel's
+// workgroups hold 4 x 112 of a SIMD's 512 registers per lane and all but 3.6 KiB of a CU's LDS for the whole launch, so a
+// neighbour has to live in 64 registers and no LDS or it only gets onto a CU by displacing one of them.  Lean by
+// construction: lanes = consecutive outputs (coalesced stores, no transpose tile); only outputs whose window lies inside
+// the call (j >= j_first; the first one or two and the mixed history for the next call come from a small launch of
+// k_mix_hb11_bank with edges_only); settled oscillator amplitude only (the host sends a call inside the transient to the
+// general kernels); and the oscillator factored out of the window, y[j] = gain * pa(j) * sum_d (h[d] step[d]) x[S j - 10 + d]
+// with pa(j) = a_inf e^{j 2 pi (phase0 + (S j - 9) inc)}: seven complex MACs and one product per output instead of
+// thirteen products and seven MACs.
+// grid ceil(n_out / (4 R 64)), block 256 (four independent waves, R outputs per lane each).
+static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *__restrict__ in, float2 *__restrict__ out, long long n_out,
+                                                                  const ChanOsc *__restrict__ osc, float a_inf, FrontTaps hb, float out_gain,
+                                                                  OscDynInline dyn, int R, long long j_first)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int S = hb.stride;
+    const ChanOsc *oc = &osc[0];
+    const double inc = oc->inc;
+    const double phase0 = dyn.use ? dyn.d[0].phase0 : oc->phase0;
+    const bool mix = (dyn.use ? dyn.d[0].mix_on : oc->mix_on) != 0;
+    float2 c2 = make_float2(hb.h[2], 0.f), c4 = make_float2(hb.h[4], 0.f), c5 = make_float2(hb.h[5], 0.f), c6 = make_float2(hb.h[6], 0.f),
+           c8 = make_float2(hb.h[8], 0.f), c10 = make_float2(hb.h[10], 0.f);
+    if (mix) {
+        c2 = cscale(oc->step[2], hb.h[2]); c4 = cscale(oc->step[4], hb.h[4]); c5 = cscale(oc->step[5], hb.h[5]);
+        c6 = cscale(oc->step[6], hb.h[6]); c8 = cscale(oc->step[8], hb.h[8]); c10 = cscale(oc->step[10], hb.h[10]);
+    }
+    const float h0 = hb.h[0];
+    const float2 rot = cis_cycles((double)(S * 64) * inc);  // this lane's output to its next one
+    const long long jb = ((long long)blockIdx.x * 4 + wv) * R * 64;
+    float2 ph = make_float2(a_inf * out_gain, 0.f);
+    for (int r = 0; r < R; r++) {
+        const long long j = jb + (long long)r * 64 + lane;
+        const long long i0 = (long long)S * j - 10;  // even
+        // (before the range test: a lane that sits out its first output must still carry the phase to its later ones)
+        if (mix) ph = r == 0 ? cscale(cis_cycles(phase0 + (double)(i0 + 1) * inc), a_inf * out_gain) : cmul(rot, ph);
+        if (j < j_first || j >= n_out) continue;
+        const float4 *p = reinterpret_cast<const float4 *>(in + i0);
+        const float4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], x5 = p[5];
+        float2 acc = cscale(make_float2(x0.x, x0.y), h0);
+        acc = cadd(acc, cmul(c2, make_float2(x1.x, x1.y)));
+        acc = cadd(acc, cmul(c4, make_float2(x2.x, x2.y)));
+        acc = cadd(acc, cmul(c5, make_float2(x2.z, x2.w)));
+        acc = cadd(acc, cmul(c6, make_float2(x3.x, x3.y)));
+        acc = cadd(acc, cmul(c8, make_float2(x4.x, x4.y)));
+        acc = cadd(acc, cmul(c10, make_float2(x5.x, x5.y)));
+        out[j] = mix ? cmul(ph, acc) : cscale(acc, out_gain);
+    }
 }
 
 // Generic real-tap FIR on complex data with decimation: the CFir post-demod filters (stride 1) and any stand-alone
