@@ -236,7 +236,7 @@ def main():
                          "measured_copy_peak_GBs": copy_gbps,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(k_ms, 4),
                          "rest_of_chain_ms": round(float(np.mean(chain_ms)), 4),
-                         "co_scheduled": "k_mix_hb11_bank (mixer + first decimation stage, HBM-bound, no LDS) runs beside this kernel on a second stream",
+                         "co_scheduled": "the chain runs on a second stream: k_mix_hb11_lean (mixer + first decimation stage, 64 registers, no LDS) beside this kernel for its first 0.19 ms, the LDS-bound rest as its workgroups finish",
                          "avg_launch_ms_alone": round(float(alone_ms), 4),
                          "frac_alone": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
