@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s through the full receive chain on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): synthetic 20 Msps HackRF-shape IQ, one tuned channel per GPU, mixer ->
+Headline workload (BASELINE.json configs[1]): synthetic 20 Msps HackRF-shape IQ, one tuned channel per GPU, mixer ->
 decimator (hb11x8, hb15, hb23, hb47 -> 312.5 kHz) -> WFM mono demod, plus the 8192-bin SignalSpectrum FFT on every
 2048-sample frame.  One "step" = one pass of that chain over one batch of `--superframes` super-frames
 (131072 samples each) already resident in HBM.
@@ -9,16 +9,26 @@ decimator (hb11x8, hb15, hb23, hb47 -> 312.5 kHz) -> WFM mono demod, plus the 81
   python bench.py [--gpus N --steps K --warmup W]           # N = 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
 
-Channels are independent: every rank owns its own stream, nothing is exchanged, so the only
-collectives are the control-plane barrier and the max-over-ranks of the elapsed time (gloo, CPU tensors) --
-weak scaling.  Rank 0 prints ONE JSON line.
+The same JSON line carries, under "configs", the other BASELINE workloads timed with the same discipline (warm-up, barrier
++ device sync, K steps, barrier + device sync, max over ranks), each with its own per-kernel HIP-event times and roofline:
+  configs[2]        2.048 Msps shared stream -> 256 tuned USB channels: mixer + hb11x4,hb15,hb19,hb31 + FastFIR 2048/1025
+                    (the full mixer -> decimate -> FastFIR -> demod chain the metric names); N = 1 only (a one-GPU config)
+  configs[3] shard  100 Msps shared stream -> 512 AM/USB channels per GPU (rank r tunes global channels [512 r, 512 r + 512))
+  configs[4] shard  128 full-rate streams per GPU: FastFIR 2048/1025 + 65536-point spectrum (rank r owns streams [128 r, ...))
+and, at N = 1, the headline fed as raw int8 pairs ("raw_int8": pebblegpu_receiver_process_raw) and the PCIe-inclusive
+rates ("pcie_inclusive", never `value`).
 
-The CPU baseline leg times the oracle (oracle/, a scalar fp64 port of the reference chain) on a bounded sample of
-the same workload; it is the only place this file touches oracle/.
+Channels / streams are independent: every rank owns its shard, nothing is exchanged, so the only
+collectives are the control-plane barrier and the max-over-ranks of the elapsed time (gloo, CPU tensors) -- weak scaling.
+Rank 0 prints ONE JSON line.  With fewer devices than ranks the run exits non-zero instead of oversubscribing a GPU.
+
+The CPU baseline leg builds and runs oracle/cpu_baseline.cpp (the oracle's scalar fp64 restatement of the reference chain,
+-O3 -march=native, std::threads over the host's cores); it is the only place this file touches oracle/.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,11 +42,12 @@ FS = 20_000_000
 NF = 2048
 BINS = 8192
 MIX_HZ = 1.0e6
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s is the measured float4-copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); the same guide measures 6.29 TB/s for a float4 copy
+C3_PER_GPU, C4_PER_GPU = 512, 128  # BASELINE.json configs[3], configs[4]: channels / streams per GPU
 
 
 def shard_streams(world, rank, per_rank=1):
-    """Static contiguous shards: rank r owns streams [r*per_rank, (r+1)*per_rank)."""
+    """Static contiguous shards: rank r owns units [r*per_rank, (r+1)*per_rank)."""
     return list(range(rank * per_rank, (rank + 1) * per_rank))
 
 
@@ -58,41 +69,50 @@ def make_input(n, seed):
     return out
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """Oracle ("port": scalar fp64 restatement of the reference chain) on this host, 1 thread."""
-    import oracle as O
-    n_frames = 64  # one super-frame at a time
-    x = make_input(n_frames * NF, 99).astype(np.complex128)
-    spec = O.Spectrum(BINS, NF)
-    mix = O.Mixer(FS)
-    mix.set_frequency(MIX_HZ)
-    dec = O.Decimator(FS, 200000)
-    dem = O.DemodWFM(312500)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        for f in range(n_frames):
-            spec.process(x[f * NF:(f + 1) * NF])
-        z = np.concatenate([dec.process(mix.process(x[i:i + 8192])) for i in range(0, len(x), 8192)])
-        dem.process(z)
-        done += len(x)
-        el = time.perf_counter() - t0
-        if el >= seconds_budget:
-            break
-    return {"value": round(done / el / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d samples (%d super-frames) of the same 20 Msps WFM+spectrum workload, %.1f s, oracle/ scalar fp64" % (done, done // len(x), el)}
+def bank_plan(fs, n_global, g):
+    """Tuning plan of the shared-stream banks: global channel g of n_global sits at (g - G/2) * 0.8 fs / G."""
+    return (g - n_global / 2.0) * (0.8 * fs / n_global)
+
+
+def make_bank_input(fs, n, freqs, seed):
+    """a tone 1.5 kHz above a sample of the channels' centres (inside each USB / AM pass-band) plus LCG noise, |x| < 0.9"""
+    from tests.signals import lcg_noise
+    rng = np.random.default_rng(seed)
+    x = lcg_noise(n, seed, 0.05).astype(np.complex64)
+    t = np.arange(n, dtype=np.float64) / fs
+    pick = freqs if len(freqs) <= 32 else [freqs[i] for i in np.linspace(0, len(freqs) - 1, 32).astype(int)]
+    for f in pick:
+        x += (0.01 * np.exp(1j * (2 * np.pi * (f + 1500.0) * t + rng.uniform(0, 2 * np.pi)))).astype(np.complex64)
+    return x
+
+
+def cpu_baseline(workload, seconds, what):
+    """oracle/cpu_baseline.cpp on this host: 1 thread and all threads."""
+    exe = os.path.join(ROOT, "oracle", "_build", "cpu_baseline")
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_build/cpu_baseline"], stdout=subprocess.DEVNULL)
+        r = json.loads(subprocess.check_output([exe, str(workload), str(seconds), "0"]).decode())
+    except Exception as e:  # no compiler on the box: say so instead of inventing a number
+        return {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": "cpu_baseline could not be built/run: %r" % (e,)}
+    return {"value": r["msamples_per_s_all_threads"], "unit": "Msamples/s", "cores": r["threads"], "kind": "port", "dtype": "f64",
+            "value_1thread": r["msamples_per_s_1thread"], "cpu_model": r["cpu_model"], "hardware_concurrency": r["hardware_concurrency"],
+            "sample": "%s: %.0f s on 1 thread, then %.0f s with the %d units spread over %d std::threads; oracle/ scalar fp64 "
+                      "(-O3 -march=native), frame loop in C++; the GPU path computes in f32" % (what, r["seconds_per_leg"], r["seconds_per_leg"], r["units"], r["threads"])}
 
 
 def pmc_traffic(superframes):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate
-    runs, gfx950 half-count correction calibrated on known-size copies): tools/pmc_workload.py + tools/parse_traffic.py,
-    stored in profiles/.  Only valid for the batch size it was measured on (256 super-frames)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if superframes != 256 or not os.path.exists(path):
-        return None
-    try:
-        return int(round(json.load(open(path))["kernels"]["k_spectrum"]["hbm_bytes"]))
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 half-count correction calibrated on known-size copies): tools/pmc_workload.py +
+    tools/parse_traffic.py.  Only valid for the batch size it was measured on (256 super-frames)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if superframes != 256 or not os.path.exists(path):
+            continue
+        try:
+            return int(round(json.load(open(path))["kernels"]["k_spectrum"]["hbm_bytes"])), "profiles/" + name + " (rocprofv3 --pmc passes of the same workload, not collected in this run)"
+        except Exception:
+            continue
+    return None, None
 
 
 def timed_steps(step, barrier, steps, dist):
@@ -121,18 +141,160 @@ def control_plane_rehearsal(args, rank, world, dist):
 
     elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), barrier, args.steps, dist)
     if dist is not None:
-        import torch
-        owned = [None] * world
+        owned, owned3, owned4 = [None] * world, [None] * world, [None] * world
         dist.all_gather_object(owned, shard)
+        dist.all_gather_object(owned3, shard_streams(world, rank, C3_PER_GPU)[::C3_PER_GPU - 1])
+        dist.all_gather_object(owned4, shard_streams(world, rank, C4_PER_GPU)[::C4_PER_GPU - 1])
     else:
-        owned = [shard]
+        owned, owned3, owned4 = [shard], [shard_streams(1, 0, C3_PER_GPU)[::C3_PER_GPU - 1]], [shard_streams(1, 0, C4_PER_GPU)[::C4_PER_GPU - 1]]
     if rank == 0:
         print(json.dumps({"metric": "control-plane rehearsal (no GPU work)", "n_gpus": world, "steps": args.steps,
                           "value": round(aggregate_msps(n * args.steps, world, elapsed), 2), "unit": "Msamples/s",
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "weak", "streams_by_rank": owned}))
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "weak", "streams_by_rank": owned,
+                          "configs3_channel_range_by_rank": owned3, "configs4_stream_range_by_rank": owned4}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_lines(groups):
+    """[(name, ms, algorithmic bytes)] -> per-kernel dict + the dominant kernel's roofline object"""
+    ks = {}
+    for name, ms, b in groups:
+        if name and ms > 0:
+            ks[name] = {"ms": round(ms, 4), "algorithmic_bytes": int(b), "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+    if not ks:
+        return ks, None
+    dom = max(ks, key=lambda k: ks[k]["ms"])
+    roof = {"bound": "hbm", "kernel": dom, "achieved": ks[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ks[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": ks[dom]["ms"],
+            "algorithmic_bytes_per_launch": ks[dom]["algorithmic_bytes"]}
+    return ks, roof
+
+
+def run_bank(P, name, fs, C, modes, k, rank, world, device, barrier, args, dist):
+    """A shared-stream bank of C channels per GPU: mixer + decimator + FastFIR + demod for every channel (no spectrum)."""
+    G = C * world
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=k, device=device)
+    freqs = []
+    for c in range(C):
+        g = rank * C + c
+        m = modes[g % len(modes)]
+        rx.set_mode(c, m)
+        f = bank_plan(fs, G, g)
+        freqs.append(f)
+        rx.set_mixer(c, f)
+        if m == P.DM_USB:
+            rx.set_bandpass(c, 300, 3000)
+        else:
+            rx.set_bandpass(c, -4000, 4000)
+    n = k * rx.superframe
+    x = make_bank_input(fs, n, freqs, 3)  # the shared wideband stream is replicated to every GPU (SURVEY.md 8e)
+    buf = P.DeviceBuffer.from_array(P.binding.to_f32_iq(x), device)
+    del x
+    for _ in range(max(2, args.warmup)):
+        rx.process_device(buf.ptr, n)
+    rx.synchronize()
+    elapsed = timed_steps(lambda: rx.process_device(buf.ptr, n), barrier, args.steps, dist)
+    # per-kernel HIP events (four more event records per call, so outside the timed region)
+    rx.set_profiling(True)
+    for _ in range(4):
+        rx.process_device(buf.ptr, n)
+    rx.synchronize()
+    ms = {w: rx.mean_ms(w, 3) for w in (2, 3, 4, 5)}
+    names = {w: rx.kernel_name(w) for w in (2, 3, 4, 5)}
+    chain = rx.chain()
+    D = rx.D
+    n_am = sum(1 for c in range(C) if modes[(rank * C + c) % len(modes)] == P.DM_AM)
+    d0 = chain[0][1] * (chain[1][1] if names[2] == "k_mix_cic_hb" else 1)
+    if names[3] == "":
+        d0 = D  # the whole decimator is one kernel: nothing is written above the demod rate
+    front_b = 8 * n + 8 * C * n // d0
+    rest_b = 8 * C * n // d0 + 8 * C * n // D
+    groups = [(names[2], ms[2], front_b), (names[3], ms[3], rest_b), (names[4], ms[4], 16 * C * n // D),
+              ("AM demod: k_iir_scan + k_fir_dec" if n_am else "", ms[5], 16 * n_am * n // D)]
+    ks, roof = kernel_lines(groups)
+    t_ms = elapsed / args.steps * 1e3
+    comp = 8 * n + 8 * C * n // D
+    actual = sum(v["algorithmic_bytes"] for v in ks.values())
+    out = {"workload": name, "fs": fs, "channels_per_gpu": C, "channels_total": G, "input_samples_per_step": n,
+           "chain": "%s (D = %d)" % (", ".join(("cic3" if t == 0 else "hb%d" % t) + ("x%d" % s if s > 2 else "") for t, s in chain), D),
+           "ms_per_step": round(t_ms, 4), "channel_Msamples_per_s": round(C * world * n / (t_ms * 1e-3) / 1e6, 1),
+           "input_Msamples_per_s": round(n / (t_ms * 1e-3) / 1e6, 1),
+           "bytes_compulsory": comp, "bytes_moved_by_kernels": actual, "moved_over_compulsory": round(actual / comp, 2),
+           "compulsory_GBps": round(comp / (t_ms * 1e-3) / 1e9, 1), "frac_of_peak_on_compulsory_bytes": round(comp / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "kernels": ks, "roofline": roof}
+    rx.close()
+    buf.free()
+    return out
+
+
+def run_streambank(P, rank, world, device, barrier, args, dist):
+    """BASELINE configs[4] shard: 128 streams per GPU, FastFIR 2048/1025 at the stream rate + 65536-point spectrum."""
+    S, N, F = C4_PER_GPU, 65536, 4
+    rng = np.random.default_rng(4 + rank)
+    x = np.empty((S, F * N), dtype=np.complex64)
+    for s in range(S):
+        x[s] = (rng.standard_normal(F * N, dtype=np.float32) + 1j * rng.standard_normal(F * N, dtype=np.float32)) * np.float32(0.1)
+    sb = P.StreamBank(2.0e6, S, frame=N, spectrum_bins=N, max_frames=F, device=device)
+    for c in range(S):
+        sb.set_bandpass(c, -50e3, 50e3)
+    buf = P.DeviceBuffer.from_array(x.view(np.float32), device)
+    del x
+    for _ in range(max(2, args.warmup)):
+        sb.process_device(buf.ptr, F * N)
+    sb.synchronize()
+    elapsed = timed_steps(lambda: sb.process_device(buf.ptr, F * N), barrier, args.steps, dist)
+    bp, sp = [], []
+    for _ in range(4):
+        sb.process_device(buf.ptr, F * N)
+        bp.append(sb.last_ms(1))
+        sp.append(sb.last_ms(2))
+    n = S * F * N
+    ks, roof = kernel_lines([("k_fastfir_t128", float(np.mean(bp[1:])), 16 * n), (sb.spectrum_kernels(), float(np.mean(sp[1:])), 12 * n)])
+    t_ms = elapsed / args.steps * 1e3
+    out = {"workload": "configs[4] shard: %d streams/GPU x %d frames of 65536, FastFIR 2048/1025 + 65536-point spectrum" % (S, F),
+           "streams_per_gpu": S, "streams_total": S * world, "samples_per_step_per_gpu": n, "ms_per_step": round(t_ms, 4),
+           "Msamples_per_s": round(n * world / (t_ms * 1e-3) / 1e6, 1), "bytes_compulsory": 28 * n,
+           "compulsory_GBps": round(28 * n / (t_ms * 1e-3) / 1e9, 1), "frac_of_peak_on_compulsory_bytes": round(28 * n / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "kernels": ks, "roofline": roof}
+    sb.close()
+    buf.free()
+    return out
+
+
+def pcie_inclusive(P, rx, n, device):
+    """What the headline workload runs at when the host hands over pageable host buffers (PCIe both ways).  Never `value`."""
+    x = P.binding.to_f32_iq(make_input(n, 1000))
+    raw = np.clip(np.round(np.asarray(x).view(np.float32).ravel() * 128), -128, 127).astype(np.int8)
+    dbuf, rbuf = P.DeviceBuffer(x.nbytes, device), P.DeviceBuffer(raw.nbytes, device)
+
+    def best(f, k=3):
+        b = 1e9
+        for _ in range(k):
+            t0 = time.perf_counter()
+            f()
+            b = min(b, time.perf_counter() - t0)
+        return b
+
+    def f_float():
+        dbuf.upload(x)
+        rx.process_device(dbuf.ptr, n)
+        rx.audio()
+
+    def f_raw():
+        rbuf.upload(raw)
+        rx.process_raw_device(rbuf.ptr, n, 0, 0, 1.0)
+        rx.audio()
+
+    f_float()
+    f_raw()
+    a, b = best(f_float), best(f_raw)
+    dbuf.free()
+    rbuf.free()
+    return {"float2_in_audio_out": {"ms": round(a * 1e3, 3), "Msamples_per_s": round(n / a / 1e6, 1)},
+            "int8_in_audio_out": {"ms": round(b * 1e3, 3), "Msamples_per_s": round(n / b / 1e6, 1)},
+            "note": "pageable host memory, hipMemcpy each way, spectra left on the device"}
 
 
 def main():
@@ -142,8 +304,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--superframes", type=int, default=256, help="super-frames (131072 samples) per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the configs[2..4] legs, the raw-int8 leg and the PCIe-inclusive rates")
     ap.add_argument("--control-plane-only", action="store_true",
-                    help="CPU rehearsal of the N>1 launch path (rendezvous, barriers, max-over-ranks, aggregation): "
+                    help="CPU rehearsal of the N>1 launch path (rendezvous, barriers, max-over-ranks, aggregation, shard ranges): "
                          "the GPU step is replaced by a rank-dependent sleep; used by tests/test_multirank_gloo.py")
     args = ap.parse_args()
 
@@ -152,7 +315,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
-        import torch
+        import torch  # noqa: F401
         import torch.distributed as dist  # control plane only: barrier + max of a CPU scalar (gloo)
         dist.init_process_group(backend="gloo")
     assert world == args.gpus or world == 1, "launch one rank per GPU (torch.distributed.run --nproc-per-node N)"
@@ -165,7 +328,12 @@ def main():
     ndev = L.pebblegpu_device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs an MI355X: libpebblegpu has no CPU path")
-    device = local_rank % ndev
+    if ndev < world or local_rank >= ndev:
+        # never two ranks on one GPU: that run would be labelled n_gpus = N while measuring something else
+        sys.stderr.write("bench.py: %d ranks but only %d HIP device(s) visible; refusing to oversubscribe\n" % (world, ndev))
+        sys.stderr.flush()
+        os._exit(3)
+    device = local_rank
 
     rx = P.ReceiverBank(FS, n_channels=1, shared_input=True, wfm=True, spectrum_bins=BINS,
                         max_superframes=args.superframes, device=device)
@@ -174,6 +342,7 @@ def main():
     n = args.superframes * sf
     x = make_input(n, 1000 * (rank + 1))
     dbuf = P.DeviceBuffer.from_array(P.binding.to_f32_iq(x), device)  # inputs resident in HBM before timing
+    raw8 = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)  # the same samples as HackRF int8 pairs
     del x
 
     def barrier():
@@ -191,6 +360,8 @@ def main():
         rx.process_device(dbuf.ptr, n)
     rx.synchronize()
     alone_ms = rx.mean_ms(1, 3)
+    alone = {w: rx.mean_ms(w, 3) for w in (2, 3, 5)}
+    alone_names = {w: rx.kernel_name(w) for w in (2, 3, 5)}
     rx.set_profiling(False)
     rx.process_device(dbuf.ptr, n)
     rx.synchronize()
@@ -201,20 +372,45 @@ def main():
     elapsed = timed_steps(step, barrier, args.steps, dist)
     # HIP events the library recorded on its stream around each kernel group of the timed steps (ring of 64 calls)
     k_ev = min(args.steps, 64)
-    spec_ms = [rx.mean_ms(1, k_ev)]
-    chain_ms = [rx.mean_ms(0, k_ev) - spec_ms[0]]
+    spec_ms = rx.mean_ms(1, k_ev)
+    chain_ms = rx.mean_ms(0, k_ev) - spec_ms
 
+    extra, raw_line, pcie = {}, None, None
+    if not args.headline_only:
+        if world == 1:
+            # the headline fed in the device's own sample format (2 B/sample in): normalizeIQ runs on the device
+            rbuf = P.DeviceBuffer.from_array(raw8, device)
+            for _ in range(2):
+                rx.process_raw_device(rbuf.ptr, n, 0, 0, 1.0)
+            rx.synchronize()
+            el = timed_steps(lambda: rx.process_raw_device(rbuf.ptr, n, 0, 0, 1.0), barrier, args.steps, dist)
+            raw_line = {"entry": "pebblegpu_receiver_process_raw(PEBBLEGPU_IQ_S8)", "bytes_in_per_sample": 2,
+                        "ms_per_step": round(el / args.steps * 1e3, 4), "Msamples_per_s": round(n * args.steps / el / 1e6, 1)}
+            rbuf.free()
+            pcie = pcie_inclusive(P, rx, n, device)
+    del raw8
+    rx_info = {"frames": n // NF}
     copy_gbps = None
     if rank == 0:
         try:
             copy_gbps = round(P.binding.probe_copy_gbps(16, 1 << 30, 10, device), 1)  # measured float4 streaming copy, read+write
         except Exception:
             copy_gbps = None
+    rx.close()
+    dbuf.free()
+    if not args.headline_only:
+        if world == 1:
+            extra["configs[2]"] = run_bank(P, "configs[2]: 2.048 Msps shared stream -> 256 tuned USB channels, mixer + decimate + FastFIR 2048/1025 (300-3000 Hz), 8 super-frames per step",
+                                           2_048_000, 256, [P.DM_USB], 8, rank, world, device, barrier, args, dist)
+        extra["configs[3] shard"] = run_bank(P, "configs[3] shard: 100 Msps shared stream -> %d AM/USB channels per GPU (global channels [%d r, %d r + %d)), 1 super-frame (4 194 304 samples) per step"
+                                             % (C3_PER_GPU, C3_PER_GPU, C3_PER_GPU, C3_PER_GPU), 100_000_000, C3_PER_GPU, [P.DM_AM, P.DM_USB], 1, rank, world, device, barrier, args, dist)
+        extra["configs[4] shard"] = run_streambank(P, rank, world, device, barrier, args, dist)
+
     if rank == 0:
-        frames = n // NF
+        frames = rx_info["frames"]
         algo_bytes = frames * (8 * NF + 4 * BINS)  # 8*N + 4*bins per frame
-        k_ms = float(np.mean(spec_ms))
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        achieved = algo_bytes / (spec_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.superframes)
         out = {
             "metric": "IQ Msamples/s through full ProcessBlock chain",
             "value": round(aggregate_msps(n * args.steps, world, elapsed), 2),
@@ -228,20 +424,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 20 Msps int8-shape IQ, 1 channel/GPU, mixer+decimate(D=64)+WFM mono demod + 8192-bin SignalSpectrum per 2048-sample frame",
+            "config": {"workload": "configs[1]: 20 Msps int8-shape IQ (values k/128, resident in HBM as float2), 1 channel/GPU, mixer+decimate(D=64)+WFM mono demod + 8192-bin SignalSpectrum per 2048-sample frame",
                        "samples_per_step_per_gpu": n, "frames_per_buffer": NF, "spectrum_bins": BINS,
                        "parallelism": "independent channel per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": "k_spectrum_t128", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.superframes),
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_peak_GBs": copy_gbps,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(k_ms, 4),
-                         "rest_of_chain_ms": round(float(np.mean(chain_ms)), 4),
-                         "co_scheduled": "the chain runs on a second stream: k_mix_hb11_lean (mixer + first decimation stage, 64 registers, no LDS) beside this kernel for its first 0.19 ms, the LDS-bound rest as its workgroups finish",
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(spec_ms, 4),
+                         "rest_of_chain_ms": round(chain_ms, 4),
+                         "co_scheduled": "the chain runs on a second stream beside this kernel (its first stage needs no LDS)",
                          "avg_launch_ms_alone": round(float(alone_ms), 4),
-                         "frac_alone": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "frac_alone": round(algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "chain_kernels_alone_ms": {alone_names[w]: round(alone[w], 4) for w in alone if alone_names[w]}},
         }
+        if raw_line:
+            out["raw_int8"] = raw_line
+        if pcie:
+            out["pcie_inclusive"] = pcie
+        if extra:
+            out["configs"] = extra
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(1, 8, "configs[1] (20 Msps WFM mono + 8192-bin spectrum per frame; one channel per thread, as one channel per GPU)")
+            if not args.headline_only:
+                for key, wl, what in (("configs[2]", 2, "the 256-channel bank"), ("configs[3] shard", 3, "the 512-channel shard, a 64-frame sample of its 2048-frame super-frame"),
+                                      ("configs[4] shard", 4, "the 128-stream shard")):
+                    if key in extra:
+                        extra[key]["cpu_baseline"] = cpu_baseline(wl, 2.5, what)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

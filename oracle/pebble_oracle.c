@@ -244,18 +244,27 @@ uint32_t po_decimator_process(po_decimator *d, const double *in, double *out, ui
  * ---------------------------------------------------------------------------------------------- */
 void po_fft(double *x, uint32_t n, int dir)
 {
-    /* twiddle table W_n^k = exp(-2*pi*i*k/n), k < n/2, computed once per size (vDSP_create_fftsetupD does the same) */
-    static uint32_t tab_n = 0;
-    static double *tab = NULL;
-    if (tab_n != n) {
-        free(tab);
+    /* twiddle table W_n^k = exp(-2*pi*i*k/n), k < n/2, computed once per size (vDSP_create_fftsetupD does the same);
+     * one small cache per thread so that several sizes and several threads (oracle/cpu_baseline.cpp) can be in use at once */
+    enum { kTabs = 8 };
+    static _Thread_local uint32_t tab_sizes[kTabs];
+    static _Thread_local double *tabs[kTabs];
+    static _Thread_local int tab_next = 0;
+    double *tab = NULL;
+    for (int i = 0; i < kTabs; i++)
+        if (tab_sizes[i] == n) tab = tabs[i];
+    if (!tab) {
+        const int slot = tab_next;
+        tab_next = (tab_next + 1) % kTabs;
+        free(tabs[slot]);
         tab = (double *)malloc((size_t)n * sizeof(double));
         for (uint32_t k = 0; k < n / 2; k++) {
             double ang = -PO_TWOPI * (double)k / (double)n;
             tab[2 * k] = cos(ang);
             tab[2 * k + 1] = sin(ang);
         }
-        tab_n = n;
+        tabs[slot] = tab;
+        tab_sizes[slot] = n;
     }
     /* bit reversal */
     for (uint32_t i = 1, j = 0; i < n; i++) {

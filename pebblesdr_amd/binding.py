@@ -17,7 +17,7 @@ SYMBOLS = [
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch", "pebblegpu_receiver_process_raw",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
-    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
+    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_kernel_name", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
     "pebblegpu_streambank_process", "pebblegpu_streambank_filtered", "pebblegpu_streambank_spectrum",
     "pebblegpu_streambank_last_ms", "pebblegpu_streambank_synchronize",
@@ -102,6 +102,8 @@ def _declare(L):
     L.pebblegpu_receiver_last_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_mean_ms.argtypes = [vp, i32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_set_profiling.argtypes = [vp, i32]
+    L.pebblegpu_receiver_kernel_name.restype = C.c_char_p
+    L.pebblegpu_receiver_kernel_name.argtypes = [vp, i32]
     L.pebblegpu_receiver_enable_signal_strength.argtypes = [vp, i32]
     L.pebblegpu_receiver_signal_strength.restype = vp
     L.pebblegpu_receiver_signal_strength.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -334,6 +336,9 @@ class ReceiverBank:
         check(self.L, self.L.pebblegpu_receiver_last_ms(self.h, which, C.byref(ms)))
         return ms.value
 
+    def kernel_name(self, which):
+        return (self.L.pebblegpu_receiver_kernel_name(self.h, which) or b"").decode()
+
     def mean_ms(self, which=0, last_k=1):
         ms = C.c_float()
         check(self.L, self.L.pebblegpu_receiver_mean_ms(self.h, which, last_k, C.byref(ms)))
@@ -432,6 +437,10 @@ class StreamBank:
         ms = C.c_float()
         check(self.L, self.L.pebblegpu_streambank_last_ms(self.h, which, C.byref(ms)))
         return ms.value
+
+    def spectrum_kernels(self):
+        """label of the kernels behind last_ms(2)"""
+        return "k_big_cols + k_big_rows" if self.frame == 65536 else "k_spectrum"
 
     def filtered(self):
         n, pitch = C.c_uint64(), C.c_uint64()

@@ -409,6 +409,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
                    len1, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
                    (const float *)osc.d_amp, osc.a_inf, wide_fir, first.stride, 1.0f, osc.inline_dyn, cl_log2, (int)C, R);
         hist_parity ^= 1;
+        front_name = "k_mix_cic_hb";
         if (after_first) PG_HIP(hipEventRecord(after_first, s));
         len_out = len1;
         src = &buf1;
@@ -421,6 +422,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             const long long j_first = (10 + first.stride - 1) / first.stride;
             launch(k_mix_hb11_lean, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc, osc.a_inf, bank_taps,
                    first.gain, osc.inline_dyn, R, j_first);
+            front_name = "k_mix_hb11_lean";
             launch(k_mix_hb11_bank<false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch, (int)shared_input, buf0.data(), buf0.pitch,
                    len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
                    (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first);
@@ -436,6 +438,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             launch_lds(kern, grid, dim3(256), cl_log2 ? 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2) : 0, s, d_in, in_pitch, (int)shared_input, buf0.data(),
                        buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
                        (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, cl_log2, (int)C, R, -1LL);
+            front_name = "k_mix_hb11_bank";
         } else {
         // merged CIC3 over a shared stream: one workgroup mixes a group of channels from one fetch of the sample pairs
         const int cg = (first.cic3 && first.stride > 2 && shared_input) ? 8 : 1;
@@ -444,6 +447,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         launch_lds(k_mix_dec1, dim3(cdiv(len0, 256), cdiv(C, cg)), dim3(256), lds, s, d_in, in_pitch, (int)shared_input, buf0.data(),
                    buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], (int)kMaxTaps, (const float *)osc.d_amp,
                    osc.a_inf, first, d_hist_mixed[hist_parity ^ 1], osc.inline_dyn, cg, (int)C);  // its last block leaves the next call's mixed history
+        front_name = "k_mix_dec1";
         }
         hist_parity ^= 1;
         if (after_first) PG_HIP(hipEventRecord(after_first, s));
@@ -455,7 +459,9 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             src = &buf1;
         }
     }
+    rest_name = wide && !fused_front ? "k_fir_dec" : "";
     if (casc.nst > 0) {
+        rest_name = wide && !fused_front ? "k_fir_dec + k_cascade" : "k_cascade";
         len_out = n / (long long)chain.total;
         launch_lds(k_cascade, dim3(cdiv(len_out, casc.outb), C), dim3(256), casc_lds_bytes, s, (const float2 *)src->data(), src->pitch, fin.data(),
                    fin.pitch, len_out, casc);

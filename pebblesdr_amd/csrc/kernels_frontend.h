@@ -716,14 +716,26 @@ static __global__ __launch_bounds__(256) void k_normalize_iq(const void *__restr
     }
 }
 
-// Bandwidth probes for the roofline (bench.py): plain streaming copies with 16-byte and 8-byte lanes.
+// Bandwidth probes for the roofline (bench.py): plain streaming copies with 16-byte and 8-byte lanes, four loads in flight
+// per work-item before the first store (one load in flight per work-item read 4.9 TB/s where the part sustains ~6.3).
+template <class V>
+__device__ __forceinline__ void probe_copy_body(const V *__restrict__ src, V *__restrict__ dst, long long n)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const V a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
 static __global__ __launch_bounds__(256) void k_probe_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+    probe_copy_body(src, dst, n);
 }
 static __global__ __launch_bounds__(256) void k_probe_copy8(const float2 *__restrict__ src, float2 *__restrict__ dst, long long n)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+    probe_copy_body(src, dst, n);
 }
 
 // All history tails of a call in one launch: buf[c][-hist + j] = buf[c][n - hist + j], j < hist, for every buffer.

@@ -227,6 +227,11 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
     *ms = (float)(sum / last_k);
     return 0;
 }
+const char *pebblegpu_receiver_kernel_name(const pebblegpu_receiver *h, int which)
+{
+    if (!h) return "";
+    return h->rx.kernel_name(which);
+}
 int pebblegpu_receiver_set_profiling(pebblegpu_receiver *h, int per_kernel)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");

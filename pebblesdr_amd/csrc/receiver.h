@@ -87,6 +87,8 @@ struct DecimCore {
     HistBuf buf1;
     long long len1 = 0;
     long long len0 = 0, len_out = 0; // lengths produced by the last run
+    const char *front_name = "";     // the kernel the last run() used for the mixer + first stage (bench / profiling labels)
+    const char *rest_name = "";      // ... and for the remaining stages
     float2 *d_hist_mixed[2] = {nullptr, nullptr};  // [C][kMaxTaps]: mixed-sample history of stage 0 (read one, write the other)
     int hist_parity = 0;
     // last_hist: head-room of the final buffer (what the consumer looks back at); last_gain: folded into the final stage
@@ -291,6 +293,7 @@ public:
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();
+    const char *kernel_name(int which) const;  // the kernels behind pebblegpu_receiver_last_ms's groups, as last run
 
     int device = 0;
     double fs = 0;

@@ -32,6 +32,9 @@ def test_two_rank_control_plane_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == steps and d["scaling"] == "weak"
     assert d["streams_by_rank"] == [[0], [1]]
+    # the banks shard the same way: rank r owns configs[3] channels [512 r, 512 r + 511] and configs[4] streams [128 r, 128 r + 127]
+    assert d["configs3_channel_range_by_rank"] == [[0, 511], [512, 1023]]
+    assert d["configs4_stream_range_by_rank"] == [[0, 127], [128, 255]]
     # rank 1 sleeps 4 ms per step, rank 0 2 ms: the reported time is the slower rank's
     assert d["ms_per_step"] >= 4.0
     # whole-job aggregate: both ranks' samples over the max time
@@ -45,3 +48,11 @@ def test_single_rank_needs_no_process_group():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["streams_by_rank"] == [[0]]
+
+
+def test_more_ranks_than_devices_is_refused():
+    """bench.py must not put two ranks on one GPU (or run at all without one): non-zero exit, no JSON line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--headline-only", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

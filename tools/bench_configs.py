@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the other BASELINE configs on one GPU (not the bench line; numbers go to profiles/README.md).
   configs[2]: 2.048 Msps shared stream -> 256 tuned SSB channels (mixer + decimate + FastFIR + pass-through demod)
   configs[3] shard: 100 Msps shared stream -> 512 AM/SSB channels"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """DEVELOPER-ONLY: per-kernel instruction mix from `hipcc -S --cuda-device-only` output.  Usage: isa_mix.py file.s [name-substring ...]"""
 import collections
 import re

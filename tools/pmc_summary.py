@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """DEVELOPER-ONLY: average PMC counter values per kernel from rocprofv3 --pmc runs (rocpd *_results.db files under a dir)."""
 import collections
 import glob

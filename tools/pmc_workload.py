@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Workload for the HBM-traffic PMC passes (run under `rocprofv3 --pmc FETCH_SIZE` and, separately, `--pmc WRITE_SIZE`):
 two calibration copies of known size (16-byte and 8-byte lanes, 1 GiB each way) followed by three steps of the
 bench workload (bench.py's configs[1] batch).  tools/parse_traffic.py turns the two CSVs into profiles/*.json."""
