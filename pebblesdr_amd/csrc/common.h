@@ -44,13 +44,21 @@ inline void launch_lds(void (*kernel)(KA...), dim3 grid, dim3 block, size_t lds_
 // scalar code makes the compiler scatter re/im over unrelated registers and gather them again with v_mov before
 // every packed instruction (a third of the VALU stream in the FFT kernels).
 __device__ __forceinline__ float2 cswap(float2 a) { return make_float2(a.y, a.x); }
+// Complex product as two packed instructions and nothing else: on the native two-element vector type the half negation
+// (-a.y, a.y) folds into the multiply's neg_lo modifier and the swap into its op_sel, also when `a` changes from use to use
+// (through float2's operators the compiler built (-a.y, a.y) with a v_xor and a v_mov per product of a varying operand).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    return make_float2(a.x, a.x) * b + make_float2(-a.y, a.y) * cswap(b);
+    const v2f_t aa = {a.x, a.x}, na = {-a.y, a.y}, bb = {b.x, b.y}, bs = {b.y, b.x};
+    const v2f_t d = __builtin_elementwise_fma(aa, bb, na * bs);
+    return make_float2(d.x, d.y);
 }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b)  // a * conj(b)
 {
-    return make_float2(b.x, b.x) * a + make_float2(b.y, -b.y) * cswap(a);
+    const v2f_t bx = {b.x, b.x}, nb = {b.y, -b.y}, av = {a.x, a.y}, as = {a.y, a.x};
+    const v2f_t d = __builtin_elementwise_fma(bx, av, nb * as);
+    return make_float2(d.x, d.y);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }

@@ -6,6 +6,7 @@
 #include "kernels_demod.h"
 #include "kernels_fastfir.h"
 #include "kernels_frontend.h"
+#include "kernels_fused_dec.h"
 #include "kernels_spectrum.h"
 #include "receiver.h"
 
@@ -357,6 +358,29 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
         }
         if (casc_lds_bytes > 150 * 1024) return fail(PEBBLEGPU_E_UNSUPPORTED, "decimation cascade does not fit LDS");
     }
+    // the whole decimator in one kernel: hb11 x S, then hb15, hb19, hb31 at stride 2 (k_mix_dec_fused<15, 19, 31>)
+    {
+        using FG = FusedDecGeom<15, 19, 31>;
+        const char *env = getenv("PEBBLEGPU_NO_FUSED_DEC");
+        fused_all = bank_front && C >= 16 && !wide && casc.nst == 3 && casc.ntaps[0] == 15 && casc.ntaps[1] == 19 && casc.ntaps[2] == 31 &&
+                    casc.stride[0] == 2 && casc.stride[1] == 2 && casc.stride[2] == 2 && first.stride <= 16 && !(env && env[0] == '1');
+        if (fused_all) {
+            fused_hy = FG::HY;
+            if (halo0 < fused_hy) halo0 = fused_hy;  // the stage-0 head-room doubles as the fused kernel's first-stage history
+            fused_p = new FusedDecParams();
+            memset(fused_p, 0, sizeof(*fused_p));
+            fused_p->S = first.stride;
+            fused_p->n_chan = (int)C;
+            fused_p->hist_pitch = kMaxTaps;
+            fused_p->gain0 = first.gain;
+            fused_p->gain = casc.gain;
+            for (int i = 0; i < 2; i++) {
+                PG_HIP(hipMalloc((void **)&d_xhist[i], sizeof(float2) * 16));
+                PG_HIP(hipMemset(d_xhist[i], 0, sizeof(float2) * 16));
+            }
+            PG_HIP(hipMalloc((void **)&d_y0stage, sizeof(float2) * (size_t)fused_hy * C));
+        }
+    }
     const long long len0 = max_in / s0.stride;
     if (ns == 1) {
         if (int rc = buf0.alloc((int)C, last_hist, len0)) return rc;
@@ -379,6 +403,14 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
 }
 void DecimCore::release()
 {
+    delete fused_p;
+    fused_p = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (d_xhist[i]) (void)hipFree(d_xhist[i]);
+        d_xhist[i] = nullptr;
+    }
+    if (d_y0stage) (void)hipFree(d_y0stage);
+    d_y0stage = nullptr;
     buf0.release();
     buf1.release();
     fin.release();
@@ -396,6 +428,34 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
     const HistBuf *src = &buf0;
+    last_fused = false;
+    if (fused_all && shared_input && !osc.any_transient()) {
+        if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+        len_out = n / (long long)chain.total;
+        const long long groups = cdiv(C, 64);
+        if (!fused_L) {
+            const char *e = getenv("PEBBLEGPU_FUSED_L");
+            fused_L = e ? atoi(e) : 0;
+            if (fused_L < 16) fused_L = -1;  // choose per call
+            fused_L &= ~15;
+        }
+        long long L = fused_L > 0 ? fused_L : ((len_out * groups / 1024 + 15) & ~15LL);  // ~one wave per SIMD; every chunk pays a warm-up
+        if (L < 32) L = 32;
+        fused_p->n_out = len_out;
+        fused_p->out_pitch = fin.pitch;
+        fused_p->y0_pitch = buf0.pitch;
+        fused_p->L = (int)L;
+        fused_p->a_inf = osc.a_inf;
+        launch(k_mix_dec_fused<15, 19, 31>, dim3(cdiv(cdiv(len_out, L), 4), (unsigned)groups), dim3(256), s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn,
+               (const float2 *)d_xhist[hist_parity], d_xhist[hist_parity ^ 1], (const float2 *)buf0.data(), d_y0stage, d_hist_mixed[hist_parity ^ 1], *fused_p);
+        PG_HIP(hipGetLastError());
+        hist_parity ^= 1;
+        front_name = "k_mix_dec_fused";
+        rest_name = "";
+        last_fused = true;
+        if (after_first) PG_HIP(hipEventRecord(after_first, s));
+        return 0;
+    }
     if (fused_front) {
         len1 = len0 / wide_stride;
         if (len1 > buf1.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
@@ -467,10 +527,18 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
                    fin.pitch, len_out, casc);
     }
     PG_HIP(hipGetLastError());
+    if (fused_all && shared_input)  // the next call may take the fused route: it wants this call's raw tail (hist_parity already flipped)
+        PG_HIP(hipMemcpyAsync(d_xhist[hist_parity], d_in + (n - 16), sizeof(float2) * 16, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
+    if (last_fused) {
+        // the call's last first-stage outputs (staged by the kernel) become the stage-0 head-room, as if the buffer had been written
+        jobs.push_back(TailJob{d_y0stage, (long long)fused_hy, (long long)fused_hy, fused_hy, 0, buf0.base + (buf0.hist - fused_hy), buf0.pitch});
+        if (fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
+        return;
+    }
     if (!fused_front && buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
     if (wide && buf1.hist > 0) jobs.push_back(TailJob{buf1.data(), buf1.pitch, len1, buf1.hist, 0, nullptr, 0});
     if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
@@ -1175,8 +1243,15 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     if (bins > 65535) bins = 65535;  // fft.cpp:76-77 (and then not a power of two)
     big = frame == (uint32_t)kBigN && fft_size == (uint32_t)kBigN;  // BASELINE config 5: past the fft.h:21 clamp on purpose
     if (big) bins = kBigN;
-    if (!big && (nf != 2048 || !(bins == 2048 || bins == 4096 || bins == 8192)))
-        return fail(PEBBLEGPU_E_UNSUPPORTED, "spectrum needs 2048-sample frames and 2048/4096/8192 bins in this build (asked %u/%u)", nf, bins);
+    const bool pow2_zp = nf == 2048 && (bins == 2048 || bins == 4096 || bins == 8192 || bins == 16384 || bins == 32768);
+    if (!big && !pow2_zp)
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "spectrum needs 2048-sample frames and 2048/4096/8192/16384/32768 bins in this build (asked %u/%u)", nf, bins);
+    // One transform per 128-item workgroup (k_spectrum_q128) serves every power-of-two zero-padding; measured against the
+    // shared-frame kernels on the bench batch it wins at 2048 bins (0.098 vs 0.105 ms) and loses at 4096 (0.198 vs 0.185) and
+    // 8192 (0.44 vs 0.28: its ZP workgroups each re-read the frame and store 4-byte bins ZP*4 bytes apart), so it runs where
+    // it wins and where nothing else exists (16384, 32768).  PEBBLEGPU_SPECTRUM_PERQ=1 forces it everywhere (A/B runs).
+    const char *env = getenv("PEBBLEGPU_SPECTRUM_PERQ");
+    per_q = !big && (bins == 2048 || bins > 8192 || (env && env[0] == '1'));
     std::vector<double> w;
     const double cg = design::blackman_harris(nf, w);
     std::vector<float> wf(nf);
@@ -1195,7 +1270,23 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
         }
     PG_HIP(hipMalloc((void **)&d_btab, sizeof(float2) * bt.size()));
     PG_HIP(hipMemcpy(d_btab, bt.data(), sizeof(float2) * bt.size(), hipMemcpyHostToDevice));
-    if (bins == 8192 && !big) {
+    if (per_q) {
+        std::vector<float2> ft((size_t)zp * nf);
+        for (uint32_t q = 0; q < zp; q++)
+            for (uint32_t n = 0; n < nf; n++) {
+                const double a = -design::kTwoPi * (double)(((uint64_t)n * q) % bins) / (double)bins;
+                ft[(size_t)q * nf + n] = make_float2((float)(w[n] * std::cos(a)), (float)(w[n] * std::sin(a)));
+            }
+        PG_HIP(hipMalloc((void **)&d_ftab, sizeof(float2) * ft.size()));
+        PG_HIP(hipMemcpy(d_ftab, ft.data(), sizeof(float2) * ft.size(), hipMemcpyHostToDevice));
+        if (int rc = make_twiddles_t128(&d_tw128)) return rc;
+    }
+    if (bins == 8192 && !big && !per_q) {
+        PG_HIP(hipMalloc((void **)&d_cu_ctr, sizeof(int) * 2048));
+        PG_HIP(hipMemset(d_cu_ctr, 0, sizeof(int) * 2048));
+        const char *e1 = getenv("PEBBLEGPU_T128_STAGGER"), *e2 = getenv("PEBBLEGPU_T128_PADLDS");
+        stagger = e1 ? atoi(e1) : 0;
+        pad_lds = e2 ? atoi(e2) : 0;
         std::vector<float2> b2(4 * 16);
         for (int q = 0; q < 4; q++)
             for (int m = 0; m < 16; m++) {
@@ -1216,8 +1307,10 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128};
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128, d_ftab, d_cu_ctr};
+    d_cu_ctr = nullptr;
     for (void *q : p) if (q) (void)hipFree(q);
+    d_ftab = nullptr;
     d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr; d_btab128 = d_tw128 = nullptr;
     y_cap = 0;
 }
@@ -1250,6 +1343,25 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         PG_HIP(hipGetLastError());
         return 0;
     }
+    if (per_q) {
+        // one (chain, q) per 128-item workgroup, eight workgroups per CU: aim at 2048 resident workgroups; every chain
+        // recomputes one frame, so chains are as long as that allows
+        const int zp = (int)(bins / nf);
+        int zl = 0;
+        while ((1 << zl) < zp) zl++;
+        long long Gq = (F * (long long)S * zp) / 2048;
+        Gq = Gq < 1 ? 1 : (Gq > 32 ? 32 : Gq);
+        sp.frames_per_group = (int)Gq;
+        sp.scale = scale;
+        sp.out_pitch = F * (long long)bins;
+        const long long chains = cdiv(F, Gq);
+        static const bool f_regs = [] { const char *e = getenv("PEBBLEGPU_SPECTRUM_FREGS"); return e && e[0] == '1'; }();
+        launch(f_regs ? k_spectrum_q128<true> : k_spectrum_q128<false>, dim3((unsigned)(8 * zp * cdiv(chains, 8)), S), dim3(128), s, d_in, d_out, (const float2 *)d_ftab, (const float2 *)d_tw128,
+               (const float *)d_prev[parity], d_prev[parity ^ 1], sp, zl);
+        parity ^= 1;
+        PG_HIP(hipGetLastError());
+        return 0;
+    }
     if (bins == 8192) {
         // two-wave transforms, one frame chain per 512-thread workgroup; all workgroups resident at once (2 per CU on 256
         // CUs) when the batch allows: every chain recomputes one frame, so longer chains also mean less repeated work
@@ -1258,8 +1370,8 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         sp.frames_per_group = (int)G8;
         sp.scale = scale;
         sp.out_pitch = F * (long long)bins;
-        launch(k_spectrum_t128, dim3(cdiv(F, G8), S), dim3(512), s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
-               (const float *)d_prev[parity], d_prev[parity ^ 1], sp);
+        launch_lds(k_spectrum_t128, dim3(cdiv(F, G8), S), dim3(512), (size_t)pad_lds, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
+                   (const float *)d_prev[parity], d_prev[parity ^ 1], sp, d_cu_ctr, stagger);
         parity ^= 1;
         PG_HIP(hipGetLastError());
         return 0;

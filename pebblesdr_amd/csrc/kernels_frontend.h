@@ -721,13 +721,14 @@ static __global__ __launch_bounds__(256) void k_normalize_iq(const void *__restr
 template <class V>
 __device__ __forceinline__ void probe_copy_body(const V *__restrict__ src, V *__restrict__ dst, long long n)
 {
-    const long long stride = (long long)gridDim.x * 256;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const V a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    // a workgroup walks 1024-element tiles (16 KiB / 8 KiB, contiguous), every work-item with four loads in flight
+    const long long tiles = n / 1024;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long long i = t * 1024 + threadIdx.x;
+        const V a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+        dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
     }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (long long i = tiles * 1024 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 static __global__ __launch_bounds__(256) void k_probe_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n)
 {

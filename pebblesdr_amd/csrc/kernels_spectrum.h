@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
                                                                  const float *__restrict__ window, const float2 *__restrict__ btab128,
                                                                  const float2 *__restrict__ tw128, const float *__restrict__ prev_in,
-                                                                 float *__restrict__ prev_out, SpectrumParams sp)
+                                                                 float *__restrict__ prev_out, SpectrumParams sp, int *__restrict__ cu_ctr, int stagger)
 {
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP, XOFF = NF / 2;
     constexpr int REGION = FftLds<NF>::kSlots;
@@ -210,6 +210,20 @@ static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *_
     float win[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) win[i] = window[tid + 512 * i];
+    // The two workgroups of a CU start together and then move in lockstep (both in their arithmetic phase, then both in their
+    // LDS phase): the frame time is the SUM of the two, not their maximum.  The second workgroup to arrive on a CU (counted
+    // per CU with one atomic; the counters only ever grow, their parity is what is read) starts `stagger` x ~1024 clocks late.
+    if (stagger > 0) {
+        __shared__ int late;
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
+            late = atomicAdd(&cu_ctr[((xcc & 7) << 8) | ((hw >> 8) & 0xFF)], 1) & 1;
+        }
+        __syncthreads();
+        if (late)
+            for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(16);
+    }
     const int t0 = (wave & 1) * 64 + lane;                                   // work-item of its transform, 0..127
     const float2 tw_lane = cis_cycles(-(double)(t0 * q) / (double)BINS);     // W_bins^{t q}
     const float2 *bq = btab128 + q * E;                                      // W_bins^{128 m q}, m < 16 (wave-uniform)
@@ -300,6 +314,108 @@ static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *_
             }
         }
         __syncthreads();  // C
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One (frame chain, q) per 128-item workgroup -- any bins = ZP * 2048, ZP = 1, 2, 4, 8, 16.
+//
+// The 512-item kernel above shares a loaded frame between its four transforms through LDS and interleaves their bins
+// through LDS again; that costs it seven workgroup-wide barriers per frame, and its counters (profiles/r02_spectrum_sq_before.txt)
+// show the two workgroups of a CU moving in lockstep: vector ALU busy 63 %, LDS 41 %, the frame time their SUM.  Here a
+// workgroup is ONE transform: the two waves that share its exchange image are the only ones its barriers involve, eight
+// such workgroups (from different chains and phases) fill a CU, and nothing is shared between the ZP transforms of a frame:
+//   * each reads the frame itself (coalesced 8-byte loads; the ZP workgroups of a chain sit on one XCD under round-robin
+//     placement -- blockIdx = 8 * (ZP * chain_hi + q) + chain_lo -- so the re-reads are L2 hits; placement is speed only);
+//   * window and pre-twiddle are ONE factor per point, F[q][n] = w[n] * W_bins^{n q} (host table, fp64-rounded), held in
+//     registers for the whole chain: one complex product per point instead of a scale and two products;
+//   * a work-item stores its 16 dB values itself, bin ZP * j + q (4-byte stores, ZP * 4 bytes apart: the ZP workgroups of
+//     the frame fill each line within microseconds of each other and the XCD's L2 merges them before write-back).
+// grid (8 * ZP * ceil(chains / 8), S), block 128; LDS 18 KiB.
+// ------------------------------------------------------------------------------------------------
+template <bool F_REGS /* hold the per-point factors in registers for the whole chain (else re-read them per frame: L1/L2 hits) */>
+static __global__ __launch_bounds__(128, 4) void k_spectrum_q128(const float2 *__restrict__ in, float *__restrict__ out,
+                                                                 const float2 *__restrict__ ftab, const float2 *__restrict__ tw128,
+                                                                 const float *__restrict__ prev_in, float *__restrict__ prev_out,
+                                                                 SpectrumParams sp, int zp_log2)
+{
+    constexpr int NF = 2048, E = 16;
+    __shared__ float2 lds[FftLds<NF>::kSlots];
+    const int t0 = threadIdx.x, s = blockIdx.y;
+    const int ZP = 1 << zp_log2, BINS = NF << zp_log2;
+    const int r = blockIdx.x >> 3;
+    const int q = r & (ZP - 1);
+    const long long chain = (long long)(r >> zp_log2) * 8 + (blockIdx.x & 7);
+    const int G = sp.frames_per_group;
+    const long long f0 = chain * G;
+    if (f0 >= sp.n_frames) return;  // workgroup-uniform (grid padding)
+    const float2 *x = in + (long long)s * sp.in_pitch;
+    float *y = out + (long long)s * sp.out_pitch;
+    float2 F[F_REGS ? E : 1];
+    if (F_REGS) {
+#pragma unroll
+        for (int m = 0; m < E; m++) F[m] = ftab[q * NF + t0 + 128 * m];
+    }
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
+    // bin ZP*j + q of j = t + 128 m unfolds to (k + BINS/2) mod BINS (fft.cpp:207-213): m < 8 lands in the upper half
+    float pa[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) pa[m] = 0.f;
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        if (f >= sp.n_frames) break;  // workgroup-uniform
+        int t = t0;
+        opaque(t);
+        if (f < 0) {  // the frame before this call: amplitudes saved by the previous call (zeros on the first)
+            const float *pp = prev_in + (long long)s * BINS + (t << zp_log2) + q;
+#pragma unroll
+            for (int m = 0; m < E; m++) pa[m] = pp[(128 * m) << zp_log2];
+            continue;
+        }
+        float2 v[E];
+        {
+            const float2 *xp = x + f * NF + t;
+#pragma unroll
+            for (int m = 0; m < E; m++) v[m] = xp[128 * m];
+            if (F_REGS) {
+#pragma unroll
+                for (int m = 0; m < E; m++) v[m] = cmul(F[m], v[m]);
+            } else {
+                const float2 *fp = ftab + q * NF + t;
+                float2 fm[E];
+#pragma unroll
+                for (int m = 0; m < E; m++) fm[m] = fp[128 * m];
+#pragma unroll
+                for (int m = 0; m < E; m++) v[m] = cmul(fm[m], v[m]);
+            }
+        }
+        fft2048_t128(v, lds, tw128, t, [] { __syncthreads(); });
+        float mag[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) mag[m] = v[m].x * v[m].x + v[m].y * v[m].y;
+#pragma unroll
+        for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_sqrtf(mag[m]);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const float a = mag[m] + pa[m];
+            pa[m] = mag[m];
+            mag[m] = a;
+        }
+        if (it >= 0) {
+#pragma unroll
+            for (int m = 0; m < E; m++) mag[m] = __builtin_amdgcn_logf(mag[m]);
+            float *yp = y + f * (long long)BINS + ((t << zp_log2) + q);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const int u = m < 8 ? ((128 * m + 1024) << zp_log2) : ((128 * (m - 8)) << zp_log2);
+                yp[u] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);
+            }
+        }
+        if (f == sp.n_frames - 1) {
+            float *pp = prev_out + (long long)s * BINS + (t << zp_log2) + q;
+#pragma unroll
+            for (int m = 0; m < E; m++) pp[(128 * m) << zp_log2] = pa[m];
+        }
     }
 }
 

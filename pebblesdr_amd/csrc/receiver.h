@@ -82,6 +82,13 @@ struct DecimCore {
     bool want_lds_free = false;      // set per call by the owner: the first kernel should leave LDS alone (it runs beside the display transform)
     bool front_is_lds_free() const { return C == 1 && (fused_front || bank_front); }
     FrontTaps bank_taps;
+    // the whole decimator in one kernel (k_mix_dec_fused): a >= 16-channel bank off one shared stream whose chain is hb11 x S
+    // followed by hb15, hb19, hb31; calls inside an oscillator transient take the two-kernel route (both keep each other's history)
+    bool fused_all = false, last_fused = false;
+    struct FusedDecParams *fused_p = nullptr;   // host copy of the kernel's parameter block
+    float2 *d_xhist[2] = {nullptr, nullptr};    // [16] raw input tail of the previous call, ping-pong with hist_parity
+    float2 *d_y0stage = nullptr;                // [C][HY] the call's last first-stage outputs, copied into buf0's head-room by the tail refresh
+    int fused_hy = 0, fused_L = 0;
     int wide_taps = 0, wide_stride = 1;
     float *d_wide_taps = nullptr;
     HistBuf buf1;
@@ -257,6 +264,10 @@ struct SpectrumCore {
     float *d_window = nullptr;
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
     float2 *d_btab128 = nullptr, *d_tw128 = nullptr;  // the same for the two-wave transform (fft_t128.h), 8192 bins
+    float2 *d_ftab = nullptr;         // [bins/nf][nf] window[n] * W_bins^{n q}: the one factor per point of k_spectrum_q128
+    int *d_cu_ctr = nullptr;          // per-CU arrival counters of k_spectrum_t128's stagger (2048 ints, only ever incremented)
+    int stagger = 0, pad_lds = 0;
+    bool per_q = false;               // k_spectrum_q128 (one transform per 128-item workgroup) instead of the shared-frame kernels
     // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): the [S][F][32][2048] intermediate
     bool big = false;
     float2 *d_Y = nullptr;

@@ -210,7 +210,7 @@ def test_wfm_mono_demod_step(gpu_lib, oracle_mod, fsw):
         off += ln
 
 
-@pytest.mark.parametrize("bins", [2048, 4096, 8192])
+@pytest.mark.parametrize("bins", [2048, 4096, 8192, 16384, 32768])
 def test_spectrum_step(gpu_lib, oracle_mod, bins):
     """fftSpectrum: window, pruned zero-pad FFT, unfold, previous-frame averaging, dB, clip."""
     import pebblesdr_amd as P
@@ -234,7 +234,7 @@ def test_spectrum_known_answer_on_device(gpu_lib):
     """The reference's own table (fft.cpp:363-369) straight from the device: -10 dB tone at 48 kHz / 1 Msps."""
     import pebblesdr_amd as P
     x = tones(1e6, 2 * 2048, [(10 ** (-10 / 20), 48000.0)])
-    for bins, want in ((2048, -10.3044), (4096, -10.1264), (8192, -10.0096)):
+    for bins, want in ((2048, -10.3044), (4096, -10.1264), (8192, -10.0096), (16384, -10.0096), (32768, -10.0002)):
         sp = P.Spectrum(bins, 1e6, 2048)
         sp.fftSpectrum(x[:2048])
         g, _ = sp.fftSpectrum(x[2048:])
