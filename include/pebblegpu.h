@@ -15,6 +15,14 @@
  *   - process_* calls are single-caller per handle (the reference calls processIQData from one
  *     consumer thread, pebblelib/producerconsumer.cpp:101-109); setters may be called from another
  *     thread and take effect at the next process call (= frame boundary).
+ *   - ASYNCHRONY: pebblegpu_receiver_process / _process_raw and pebblegpu_streambank_process only QUEUE their kernels on
+ *     streams private to the handle and return.  The device buffers behind pebblegpu_receiver_audio / _spectrum /
+ *     _signal_strength and pebblegpu_streambank_filtered / _spectrum hold the call's results, and the call's INPUT buffer
+ *     may be overwritten, only after pebblegpu_receiver_synchronize / pebblegpu_streambank_synchronize (or any of
+ *     pebblegpu_memcpy_h2d / _d2h / pebblegpu_device_synchronize, which wait for all work queued on the device first).
+ *     A host that touches those buffers with its own HIP calls must synchronise itself.  Calls on one handle execute in
+ *     the order they were made.  The host-buffer entry points (pebblegpu_process_iq and every stand-alone step) return
+ *     with their results complete.
  *   - the library owns every device buffer it returns; host pointers returned by *_result() stay
  *     valid until the next process call on the same handle (ProcessStep ownership rule,
  *     application/processstep.cpp:12-20).  Inputs are never modified (receiver.cpp:747-755).
@@ -58,6 +66,7 @@ int pebblegpu_device_count(void);
  * ---------------------------------------------------------------------------------------------- */
 int pebblegpu_malloc(int device, size_t bytes, void **dptr);
 int pebblegpu_free(int device, void *dptr);
+/* both copies first wait for all work queued on the device (the library's private streams included), then copy and block */
 int pebblegpu_memcpy_h2d(int device, void *dst, const void *src, size_t bytes);
 int pebblegpu_memcpy_d2h(int device, void *dst, const void *src, size_t bytes);
 int pebblegpu_memset(int device, void *dst, int value, size_t bytes);
@@ -102,7 +111,11 @@ typedef struct {
                                     Key_AudioOutputSampleRate (receiver.cpp:203, default 11025): the audio buffer is
                                     CFractResampler::Resample(n, demodRate / audio_rate, ...) of the demodulated frames
                                     (receiver.cpp:994-1001, pebblelib/fractresampler.cpp:149-195) */
-    uint32_t reserved[4];
+    uint32_t hires_bins;         /* 0: no zoomed spectrum (m_useHiRes off); else the bin count of SignalSpectrum::zoomed
+                                    (application/signalspectrum.cpp:89-113; settings.cpp:61 default 2048): fftSpectrum, BlackmanHarris
+                                    over frames_per_buffer samples, of every DECIMATED frame of every channel -- m_sampleBuf at the
+                                    demodulator rate, after the gain restore on the narrow branch (receiver.cpp:884, 942) */
+    uint32_t reserved[3];
 } pebblegpu_config;
 
 int pebblegpu_receiver_create(const pebblegpu_config *cfg, pebblegpu_receiver **out);
@@ -147,6 +160,10 @@ int pebblegpu_set_agc(pebblegpu_receiver *rx, uint32_t channel, int agc_mode, in
  *   audio    [channel][k * frames_per_buffer] float2  (re = left, im = right, receiver.cpp:1029); with audio_rate
  *            set, the resampled audio instead: the count pebblegpu_receiver_audio reports (same for all channels)
  *   spectrum [stream][n_samples / frames_per_buffer][bins] float, dB amplitude, -f..+f (fft.cpp:395) */
+/* Frames shorter than a stage's tap count: the library streams with exact history for any n_samples that is a whole number of
+ * super-frames.  The reference, fed 2048-sample frames at >= 20 Msps, degrades such stages to unfiltered sample dropping and
+ * refills their history from indeterminate memory (pebblelib/decimator.cpp:602-625); that fallback is NOT reproduced (DESIGN.md
+ * section 4, tests/test_parity_gpu.py::test_decimator_short_frames_stream_exactly).  Queues and returns: see ASYNCHRONY above. */
 int pebblegpu_receiver_process(pebblegpu_receiver *rx, const void *d_iq, uint64_t n_samples);
 /* The same call fed with the device's own sample format (what ProducerConsumer hands normalizeIQ,
  * deviceinterfacebase.cpp:648-838): d_raw holds n_streams x n_samples raw IQ pairs, stream-major, in `format`
@@ -157,6 +174,8 @@ int pebblegpu_receiver_process_raw(pebblegpu_receiver *rx, int format, int iq_or
 /* returns channel 0's row; channel c starts *pitch_samples float2 further per channel */
 const void *pebblegpu_receiver_audio(const pebblegpu_receiver *rx, uint64_t *samples_per_channel, uint64_t *pitch_samples);
 const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *frames_per_stream);
+/* the zoomed (hi-res) spectra of the last call: [channel][frames_per_channel][bins] float dB, -f..+f at the demodulator rate */
+const void *pebblegpu_receiver_zoom_spectrum(const pebblegpu_receiver *rx, uint64_t *frames_per_channel, uint32_t *bins);
 /* Time of the last process call's kernels in ms, from HIP events on the library's stream.  which: 0 whole
  * call; 1 spectrum kernel; 2 mixer+first-decimator kernel; 3 remaining decimator stages; 4 FastFIR;
  * 5 demod. */
@@ -198,6 +217,7 @@ const void *pebblegpu_receiver_signal_strength(const pebblegpu_receiver *rx, uin
  * (PEBBLEGPU_E_UNSUPPORTED otherwise: a bank would need per-channel stream lengths behind the gate).  Turns the S-meter
  * on; needs spectrum_bins != 0 and a spectrum in the same or an earlier call. */
 int pebblegpu_set_squelch(pebblegpu_receiver *rx, uint32_t channel, double squelch_db);
+/* waits until every process call made on this handle has finished: its outputs are then valid and its input may be reused */
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);
 
 /* Host single-frame path with the reference's callback shape:

@@ -1295,7 +1295,9 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
     if (r->squelch_db > -120.0 && r->last_spec) { /* :959-965: m_avgDb < m_squelchDb -> return, nothing behind it runs */
         if (po_fd_estimate(r->last_spec, (int)r->spec_bins, r->fs, (float)r->bp_lo, (float)r->bp_hi, r->mixer_freq, NULL) < r->squelch_db) return 0;
     }
-    if (r->mode == PO_NONE) { memset(audio, 0, (size_t)nb * 2 * sizeof(double)); return (uint32_t)nb; } /* :968-971 */
+    /* :968-971 "Tune only mode, no demod or output": clearCPX(m_audioBuf) and return -- before NoiseFilter, AGC, Demod, the
+     * resampler and the audio callback, so nothing is delivered and their states stay where they were */
+    if (r->mode == PO_NONE) return 0;
     /* :974 NoiseFilter (ANF) */
     if (r->anf_on) po_anf_process(&r->anf, r->bpout, r->bpout, nb);
     /* :983 AGC, written back over the band-pass output buffer */

@@ -16,7 +16,7 @@ SYMBOLS = [
     "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps", "pebblegpu_normalize_iq",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch", "pebblegpu_receiver_process_raw",
-    "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum",
+    "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum", "pebblegpu_receiver_zoom_spectrum",
     "pebblegpu_receiver_last_ms", "pebblegpu_receiver_kernel_name", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
     "pebblegpu_streambank_process", "pebblegpu_streambank_filtered", "pebblegpu_streambank_spectrum",
@@ -42,8 +42,8 @@ class Config(C.Structure):
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("sample_rate", C.c_double),
         ("frames_per_buffer", C.c_uint32), ("n_channels", C.c_uint32), ("shared_input", C.c_uint32),
         ("wfm", C.c_uint32), ("spectrum_bins", C.c_uint32), ("fastfir_fft", C.c_uint32),
-        ("fastfir_taps", C.c_uint32), ("max_superframes", C.c_uint32), ("audio_rate", C.c_uint32),
-        ("reserved", C.c_uint32 * 4),
+        ("fastfir_taps", C.c_uint32), ("max_superframes", C.c_uint32), ("audio_rate", C.c_uint32), ("hires_bins", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
     ]
 
 
@@ -99,6 +99,8 @@ def _declare(L):
     L.pebblegpu_receiver_audio.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.pebblegpu_receiver_spectrum.restype = vp
     L.pebblegpu_receiver_spectrum.argtypes = [vp, C.POINTER(u64)]
+    L.pebblegpu_receiver_zoom_spectrum.restype = vp
+    L.pebblegpu_receiver_zoom_spectrum.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
     L.pebblegpu_receiver_last_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_mean_ms.argtypes = [vp, i32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_set_profiling.argtypes = [vp, i32]
@@ -241,7 +243,7 @@ class ReceiverBank:
     """C tuned channels over one shared stream or C independent streams (pebblegpu_receiver_*)."""
 
     def __init__(self, sample_rate, n_channels=1, shared_input=True, wfm=False, spectrum_bins=0,
-                 frames_per_buffer=2048, fastfir_fft=0, fastfir_taps=0, max_superframes=1, device=0, lib=None, audio_rate=0):
+                 frames_per_buffer=2048, fastfir_fft=0, fastfir_taps=0, max_superframes=1, device=0, lib=None, audio_rate=0, hires_bins=0):
         self.L = lib or load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -256,6 +258,7 @@ class ReceiverBank:
         cfg.fastfir_taps = fastfir_taps
         cfg.max_superframes = max_superframes
         cfg.audio_rate = audio_rate
+        cfg.hires_bins = hires_bins
         self.h = C.c_void_p()
         check(self.L, self.L.pebblegpu_receiver_create(C.byref(cfg), C.byref(self.h)))
         self.device = device
@@ -363,6 +366,16 @@ class ReceiverBank:
         self.synchronize()
         out = np.empty((self.n_streams, frames, self.bins), dtype=np.float32)
         check(self.L, self.L.pebblegpu_memcpy_d2h(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes))
+        return out
+
+    def zoom_spectrum(self):
+        """-> float32 [C, frames, hires_bins]: SignalSpectrum::zoomed of every decimated frame of the last call"""
+        f, b = C.c_uint64(), C.c_uint32()
+        p = self.L.pebblegpu_receiver_zoom_spectrum(self.h, C.byref(f), C.byref(b))
+        self.synchronize()
+        out = np.empty((self.n_channels, int(f.value), int(b.value)), dtype=np.float32)
+        if out.size:
+            check(self.L, self.L.pebblegpu_memcpy_d2h(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes))
         return out
 
     def process(self, iq):

@@ -994,7 +994,7 @@ int AgcCore::apply(hipStream_t s)
     }
     list.clear();
     for (uint32_t c = 0; c < C; c++)
-        if (host[c].mode != 0 || host[c].manual != 1.0) list.push_back((int)c);
+        if ((host[c].mode != 0 || host[c].manual != 1.0) && !(c < muted.size() && muted[c])) list.push_back((int)c);
     if (!list.empty()) PG_HIP(hipMemcpyAsync(d_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, s));
     PG_HIP(hipStreamSynchronize(s));
     list_dirty = false;
@@ -1132,7 +1132,7 @@ int AnfCore::apply(hipStream_t s)
 {
     if (!dirty) return 0;
     list.clear();
-    for (uint32_t c = 0; c < C; c++) if (on[c]) list.push_back((int)c);
+    for (uint32_t c = 0; c < C; c++) if (on[c] && !(c < muted.size() && muted[c])) list.push_back((int)c);
     PG_HIP(hipStreamSynchronize(s));
     if (!list.empty()) PG_HIP(hipMemcpy(d_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
     dirty = false;
@@ -1282,10 +1282,8 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
         if (int rc = make_twiddles_t128(&d_tw128)) return rc;
     }
     if (bins == 8192 && !big && !per_q) {
-        PG_HIP(hipMalloc((void **)&d_cu_ctr, sizeof(int) * 2048));
-        PG_HIP(hipMemset(d_cu_ctr, 0, sizeof(int) * 2048));
         const char *e1 = getenv("PEBBLEGPU_T128_STAGGER"), *e2 = getenv("PEBBLEGPU_T128_PADLDS");
-        stagger = e1 ? atoi(e1) : 0;
+        stagger = e1 ? atoi(e1) : 3;  // measured on the bench batch: 0.300 ms as two 512-item workgroups per CU, 0.278 with the halves three intervals apart
         pad_lds = e2 ? atoi(e2) : 0;
         std::vector<float2> b2(4 * 16);
         for (int q = 0; q < 4; q++)
@@ -1307,8 +1305,7 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128, d_ftab, d_cu_ctr};
-    d_cu_ctr = nullptr;
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128, d_ftab};
     for (void *q : p) if (q) (void)hipFree(q);
     d_ftab = nullptr;
     d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr; d_btab128 = d_tw128 = nullptr;
@@ -1321,7 +1318,14 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
     sp.n_frames = F;
     if (big) {
         if (F == 0) return 0;
-        const size_t need = (size_t)S * (size_t)F * kBigN;
+        // The four-step intermediate Y (8 bytes per point, written by pass A, read by pass B) is kept on the die: streams are
+        // processed in batches whose Y fits well inside the 256 MiB Infinity Cache together with the batch's own input and output
+        // (one 64 MiB buffer reused by every batch), instead of a call-sized Y that went out to HBM and back
+        // (28 B moved per 12 B of algorithmic traffic).
+        const long long per_stream = (long long)F * kBigN;                       // Y points per stream
+        long long bs = (64LL << 20) / (long long)sizeof(float2) / per_stream;    // streams per batch
+        bs = bs < 1 ? 1 : (bs > (long long)S ? (long long)S : bs);
+        const size_t need = (size_t)bs * (size_t)per_stream;
         if (need > y_cap) {
             PG_HIP(hipStreamSynchronize(s));
             if (d_Y) (void)hipFree(d_Y);
@@ -1331,14 +1335,17 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
             y_cap = need;
         }
         // a chain that does not start at frame 0 recomputes one frame: prefer chains as long as keeps >= 512 workgroups
-        long long G = (F * (long long)S * 8) / 512;
+        long long G = (F * bs * 8) / 512;
         G = G < 1 ? 1 : (G > 16 ? 16 : G);
         sp.frames_per_group = (int)G;
         sp.scale = scale;
         sp.out_pitch = F * (long long)bins;
-        launch(k_big_cols, dim3((unsigned)(F * 8), S), dim3(256), s, d_in, (long long)in_pitch, d_Y, (const float *)d_window, (long long)F);
-        launch(k_big_rows, dim3((unsigned)(cdiv(F, G) * 8), S), dim3(256), s, (const float2 *)d_Y, d_out, (const float2 *)d_tw_nf,
-               (const float *)d_prev[parity], d_prev[parity ^ 1], sp);
+        for (long long s0 = 0; s0 < (long long)S; s0 += bs) {
+            const unsigned nb = (unsigned)((long long)S - s0 < bs ? (long long)S - s0 : bs);
+            launch(k_big_cols, dim3((unsigned)(F * 8), nb), dim3(256), s, d_in + s0 * in_pitch, (long long)in_pitch, d_Y, (const float *)d_window, (long long)F);
+            launch(k_big_rows, dim3((unsigned)(cdiv(F, G) * 8), nb), dim3(256), s, (const float2 *)d_Y, d_out + s0 * sp.out_pitch, (const float2 *)d_tw_nf,
+                   (const float *)d_prev[parity] + s0 * kBigN, d_prev[parity ^ 1] + s0 * kBigN, sp);
+        }
         parity ^= 1;
         PG_HIP(hipGetLastError());
         return 0;
@@ -1370,8 +1377,12 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         sp.frames_per_group = (int)G8;
         sp.scale = scale;
         sp.out_pitch = F * (long long)bins;
-        launch_lds(k_spectrum_t128, dim3(cdiv(F, G8), S), dim3(512), (size_t)pad_lds, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
-                   (const float *)d_prev[parity], d_prev[parity ^ 1], sp, d_cu_ctr, stagger);
+        if (stagger > 0)  // two chains per 1024-item workgroup, the second `stagger` barrier intervals behind the first
+            launch(k_spectrum_t128<2>, dim3(cdiv(cdiv(F, G8), 2), S), dim3(1024), s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
+                   (const float *)d_prev[parity], d_prev[parity ^ 1], sp, stagger);
+        else
+            launch_lds(k_spectrum_t128<1>, dim3(cdiv(F, G8), S), dim3(512), (size_t)pad_lds, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
+                       (const float *)d_prev[parity], d_prev[parity ^ 1], sp, 0);
         parity ^= 1;
         PG_HIP(hipGetLastError());
         return 0;

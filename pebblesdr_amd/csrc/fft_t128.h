@@ -39,12 +39,13 @@ __device__ __forceinline__ void dft16(float2 *u)
 }
 
 // sync(): a barrier over (at least) the 128 work-items of this transform, executed by all of them.
-template <class Sync>
+// DO_LDS / DO_MATH exist for tools/ubench/fft_core.hip only (the exchanges alone, the butterflies alone); kernels use the defaults.
+template <class Sync, bool DO_LDS = true, bool DO_MATH = true>
 __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const float2 *__restrict__ tw, int t, Sync sync)
 {
     // ---- pass A: radix 16, the 16 strided elements of a work-item are one butterfly; output k -> element 16 t + k ----
-    dft16(x);
-    {
+    if (DO_MATH) dft16(x);
+    if (DO_LDS) {
         float2 *wp = lds + lpad4(16 * t);  // one pad slot per 16: work-item stride 17 slots, 16 of them cover all banks
 #pragma unroll
         for (int k = 0; k < 16; k++) wp[k] = x[perm16(k)];
@@ -54,7 +55,7 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
     {
         const int k = t & 15;
         const float2 w1 = tw[kTw128B + k], w2 = tw[kTw128B + 16 + k], w4 = tw[kTw128B + 32 + k];
-        {
+        if (DO_LDS) {
             const float2 *rp = lds + lpad4(t);  // lpad4(t + 128 m) = lpad4(t) + 136 m
 #pragma unroll
             for (int m = 0; m < 16; m++) x[m] = rp[136 * m];
@@ -67,24 +68,32 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
             float2 u[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) u[r] = x[q + 2 * r];
-            u[1] = cmul(w1, u[1]); u[2] = cmul(w2, u[2]); u[3] = cmul(w3, u[3]); u[4] = cmul(w4, u[4]);
-            u[5] = cmul(w5, u[5]); u[6] = cmul(w6, u[6]); u[7] = cmul(w7, u[7]);
-            bfly8<+1>(u);
+            if (DO_MATH) {
+                u[1] = cmul(w1, u[1]); u[2] = cmul(w2, u[2]); u[3] = cmul(w3, u[3]); u[4] = cmul(w4, u[4]);
+                u[5] = cmul(w5, u[5]); u[6] = cmul(w6, u[6]); u[7] = cmul(w7, u[7]);
+                bfly8<+1>(u);
+            }
             float2 *wp = wbase + lpad(1024 * q);
+            if (DO_LDS) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) wp[lpad(16 * r)] = u[r];  // (j mod 32) + (16 r mod 32) never carries: j mod 32 < 16
+                for (int r = 0; r < 8; r++) wp[lpad(16 * r)] = u[r];  // (j mod 32) + (16 r mod 32) never carries: j mod 32 < 16
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) x[q + 2 * r] = u[r];
+            }
         }
     }
     sync();
     // ---- pass C: radix 16, P = 128 = T, k = t; output r -> element t + 128 r (the register layout) ----
     {
         const float2 w1 = tw[kTw128C + t], w2 = tw[kTw128C + 128 + t], w4 = tw[kTw128C + 256 + t], w8 = tw[kTw128C + 384 + t];
-        {
+        if (DO_LDS) {
             const float2 *rp = lds + lpad(t);  // lpad(t + 128 m) = lpad(t) + 144 m
 #pragma unroll
             for (int m = 0; m < 16; m++) x[m] = rp[144 * m];
         }
         sync();  // the image may be overwritten (the caller parks its results there)
+        if (!DO_MATH) return;
         const float2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
         x[1] = cmul(w1, x[1]); x[2] = cmul(w2, x[2]); x[3] = cmul(w3, x[3]); x[4] = cmul(w4, x[4]);
         x[5] = cmul(w5, x[5]); x[6] = cmul(w6, x[6]); x[7] = cmul(w7, x[7]); x[8] = cmul(w8, x[8]);

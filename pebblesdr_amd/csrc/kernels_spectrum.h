@@ -186,44 +186,40 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 // 8192 bins on the two-wave transform (fft_t128.h): a workgroup of 512 = 4 transforms (q = 0..3) x 2 waves handles one
 // frame at a time; 16 points and 16 previous amplitudes per work-item instead of 32 + 32, so four waves fit a SIMD
 // (LDS: the same four 18 KiB exchange images, two workgroups per CU).  Seven workgroup barriers per frame.
-// grid (ceil(F / G), S), block 512.
+// grid (ceil(F / G) / HALVES, S), block 512 * HALVES.
 // ------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
+//
+// HALVES = 2: a 1024-item workgroup = two such halves, each with its own frame chain and its own four images (one workgroup
+// per CU, 152 KiB of LDS).  Two 512-item workgroups sharing a CU run in lockstep -- both in their arithmetic phase, then both
+// in their LDS phase: a workgroup alone takes 0.33 ms for the bench batch, two per CU 0.30 (profiles/r02_spectrum_sq_before.txt:
+// vector ALU busy 63 %, LDS 41 %, the frame time their SUM).  Here the barriers are common to both halves and the second half
+// runs `shift` barrier intervals behind the first, so that in every interval one half's butterflies meet the other's exchange:
+// the offset is fixed by construction, not left to the dispatcher.
+template <int HALVES>
+static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
                                                                  const float *__restrict__ window, const float2 *__restrict__ btab128,
                                                                  const float2 *__restrict__ tw128, const float *__restrict__ prev_in,
-                                                                 float *__restrict__ prev_out, SpectrumParams sp, int *__restrict__ cu_ctr, int stagger)
+                                                                 float *__restrict__ prev_out, SpectrumParams sp, int shift)
 {
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP, XOFF = NF / 2;
     constexpr int REGION = FftLds<NF>::kSlots;
-    __shared__ float2 lds[4][REGION];
+    __shared__ float2 lds_all[HALVES][4][REGION];
     __shared__ float2 tw_lds[kTw128Count];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 511, lane = tid & 63;
+    const int half = HALVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0;
+    float2 (*lds)[REGION] = lds_all[half];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wave >> 1, s = blockIdx.y;
     const int G = sp.frames_per_group;
-    const long long f0 = (long long)blockIdx.x * G;
+    const long long f0 = ((long long)blockIdx.x * HALVES + half) * G;
     const float2 *x = in + (long long)s * sp.in_pitch;
     float *y = out + (long long)s * sp.out_pitch;
     float2 *my = lds[q];
     float *stage = reinterpret_cast<float *>(my);
-    for (int i = tid; i < kTw128Count; i += 512) tw_lds[i] = tw128[i];
+    for (int i = threadIdx.x; i < kTw128Count; i += 512 * HALVES) tw_lds[i] = tw128[i];
     float win[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) win[i] = window[tid + 512 * i];
-    // The two workgroups of a CU start together and then move in lockstep (both in their arithmetic phase, then both in their
-    // LDS phase): the frame time is the SUM of the two, not their maximum.  The second workgroup to arrive on a CU (counted
-    // per CU with one atomic; the counters only ever grow, their parity is what is read) starts `stagger` x ~1024 clocks late.
-    if (stagger > 0) {
-        __shared__ int late;
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
-            late = atomicAdd(&cu_ctr[((xcc & 7) << 8) | ((hw >> 8) & 0xFF)], 1) & 1;
-        }
-        __syncthreads();
-        if (late)
-            for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(16);
-    }
     const int t0 = (wave & 1) * 64 + lane;                                   // work-item of its transform, 0..127
     const float2 tw_lane = cis_cycles(-(double)(t0 * q) / (double)BINS);     // W_bins^{t q}
     const float2 *bq = btab128 + q * E;                                      // W_bins^{128 m q}, m < 16 (wave-uniform)
@@ -243,6 +239,8 @@ static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *_
         }
     }
     __syncthreads();
+    if (HALVES > 1 && half == 1)
+        for (int i = 0; i < shift; i++) __syncthreads();  // the second half runs `shift` intervals behind (same barrier count overall)
     for (int it = -1; it < G; it++) {
         const long long f = f0 + it;
         const bool live = f < sp.n_frames;   // workgroup-uniform
@@ -295,6 +293,9 @@ static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *_
 #pragma unroll
                 for (int m = 0; m < E; m++) pp[ZP * 128 * m] = pa[m];
             }
+        } else if (HALVES > 1) {  // the halves share every barrier: an iteration without a transform still passes its four
+#pragma unroll
+            for (int i = 0; i < 4; i++) __syncthreads();
         }
         __syncthreads();  // B
         if (fetch) park(td);
@@ -315,6 +316,8 @@ static __global__ __launch_bounds__(512, 2) void k_spectrum_t128(const float2 *_
         }
         __syncthreads();  // C
     }
+    if (HALVES > 1 && half == 0)
+        for (int i = 0; i < shift; i++) __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,15 +46,20 @@ int pebblegpu_free(int device, void *dptr)
     PG_HIP(hipFree(dptr));
     return 0;
 }
+// The receiver and stream-bank objects queue their work on private non-blocking streams, which a null-stream hipMemcpy does
+// not order against: both copies first wait for everything queued on the device, so a host that refills an input buffer or
+// reads an output through them can never race a process call (they block anyway; the wait is what makes them safe).
 int pebblegpu_memcpy_h2d(int device, void *dst, const void *src, size_t bytes)
 {
     if (int rc = need_device(device)) return rc;
+    PG_HIP(hipDeviceSynchronize());
     PG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 int pebblegpu_memcpy_d2h(int device, void *dst, const void *src, size_t bytes)
 {
     if (int rc = need_device(device)) return rc;
+    PG_HIP(hipDeviceSynchronize());
     PG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -186,6 +191,13 @@ const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *h, uint64_t *f
     if (!h) return nullptr;
     if (frames_per_stream) *frames_per_stream = h->rx.last_spec_frames;
     return h->rx.d_spec;
+}
+const void *pebblegpu_receiver_zoom_spectrum(const pebblegpu_receiver *h, uint64_t *frames_per_channel, uint32_t *bins)
+{
+    if (!h || !h->rx.zoom_bins) return nullptr;
+    if (frames_per_channel) *frames_per_channel = h->rx.last_zoom_frames;
+    if (bins) *bins = h->rx.zoom_bins;
+    return h->rx.d_zoom;
 }
 int pebblegpu_receiver_enable_signal_strength(pebblegpu_receiver *h, int on)
 {

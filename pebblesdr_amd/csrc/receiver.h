@@ -198,6 +198,8 @@ struct AgcCore {
     int init(uint32_t channels, double demod_rate);
     void release();
     int set_mode(uint32_t ch, int mode, int threshold);      // AGC::setAgcMode, agc.cpp:53-82
+    std::vector<char> muted;        // channels the owner keeps out of the list (dmNONE: the reference returns before the AGC)
+    void set_muted(uint32_t ch, bool m) { if (muted.size() != C) muted.assign(C, 0); if ((muted[ch] != 0) != m) { muted[ch] = m; list_dirty = true; } }
     int apply(hipStream_t s);                                // upload changed parameters and the channel list
     int run(hipStream_t s, float2 *buf, long long pitch, long long n);
     bool list_dirty = false;
@@ -231,8 +233,9 @@ struct AnfCore {
     struct AnfState *d_state = nullptr;
     int *d_list = nullptr;
     std::vector<int> list;
-    std::vector<char> on;
+    std::vector<char> on, muted;   // muted: dmNONE channels (the reference returns before the noise filter)
     bool dirty = false;
+    void set_muted(uint32_t ch, bool m) { if (muted.size() != C) muted.assign(C, 0); if ((muted[ch] != 0) != m) { muted[ch] = m; dirty = true; } }
     int init(uint32_t channels);
     void release();
     int set(uint32_t ch, bool enable);
@@ -265,8 +268,7 @@ struct SpectrumCore {
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
     float2 *d_btab128 = nullptr, *d_tw128 = nullptr;  // the same for the two-wave transform (fft_t128.h), 8192 bins
     float2 *d_ftab = nullptr;         // [bins/nf][nf] window[n] * W_bins^{n q}: the one factor per point of k_spectrum_q128
-    int *d_cu_ctr = nullptr;          // per-CU arrival counters of k_spectrum_t128's stagger (2048 ints, only ever incremented)
-    int stagger = 0, pad_lds = 0;
+    int stagger = 0, pad_lds = 0;     // k_spectrum_t128: barrier intervals between the two halves of a 1024-item workgroup (0: 512-item workgroups)
     bool per_q = false;               // k_spectrum_q128 (one transform per 128-item workgroup) instead of the shared-frame kernels
     // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): the [S][F][32][2048] intermediate
     bool big = false;
@@ -317,6 +319,10 @@ public:
     Timers tm;
     HistBuf audio;   // [C][k*nf]
     float *d_spec = nullptr;
+    // SignalSpectrum::zoomed (signalspectrum.cpp:89-113): the display transform of every decimated frame of every channel
+    uint32_t zoom_bins = 0;
+    float *d_zoom = nullptr;          // [C][max_sf * superframe / (D * nf)][zoom_bins]
+    uint64_t last_zoom_frames = 0;
     // SignalStrength::fdEstimate per frame (S-meter): enabled on request, needs the spectrum
     bool smeter_on = false;
     float4 *d_smeter = nullptr;       // [C][max frames]
@@ -326,6 +332,7 @@ public:
     double squelch_db_ = -120.0;      // DB::minDb: the gate never closes (receiverwidget.cpp:82)
     float4 *h_gate_ = nullptr;        // pinned: the S-meter value the gate reads back
     uint64_t squelched_calls = 0;
+    bool failed_ = false;             // a process call failed after it had started queueing work: the handle is refused from then on
     bool profile_detail = false;      // record the per-kernel events too (pebblegpu_receiver_set_profiling)
     uint32_t audio_rate = 0;          // 0: audio stays at the demod rate (the resampRate == 1 branch, receiver.cpp:1000-1003)
     float2 *d_audio_rs = nullptr;     // [C][rs_pitch] resampled audio
@@ -363,7 +370,7 @@ private:
     ConditionCore cond_;
     AnfCore anf_;
     ResampCore resamp_;
-    SpectrumCore spec_;
+    SpectrumCore spec_, zoom_;
     float2 *d_stage_in_ = nullptr;
     float2 *d_raw_stage_ = nullptr;   // process_raw: the normalised copy of a raw device-format call (allocated on first use)
     std::vector<float> h_frame_, h_out_;

@@ -78,6 +78,13 @@ int Receiver::create(const pebblegpu_config *cfg)
         bins = spec_.bins;
         PG_HIP(hipMalloc((void **)&d_spec, sizeof(float) * (size_t)(max_n / nf) * bins * S));
     }
+    zoom_bins = cfg->hires_bins;
+    if (zoom_bins) {  // m_fftHiRes->fftParams(m_numHiResSpectrumBins, maxDb, m_hiResSampleRate, numSamples, BLACKMANHARRIS), signalspectrum.cpp:59
+        if (nd_max % nf != 0) return fail(PEBBLEGPU_E_UNSUPPORTED, "the zoomed spectrum needs whole frames at the demodulator rate");
+        if (int rc = zoom_.init(C, nf, zoom_bins)) return rc;
+        zoom_bins = zoom_.bins;
+        PG_HIP(hipMalloc((void **)&d_zoom, sizeof(float) * (size_t)(nd_max / nf) * zoom_bins * C));
+    }
     return 0;
 }
 
@@ -86,7 +93,8 @@ Receiver::~Receiver()
     (void)hipSetDevice(device);
     if (chain_stream_) (void)hipStreamSynchronize(chain_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release();
+    osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release(); zoom_.release();
+    if (d_zoom) (void)hipFree(d_zoom);
     agc_.release(); resamp_.release(); cond_.release(); anf_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
     if (h_gate_) (void)hipHostFree(h_gate_);
@@ -122,6 +130,10 @@ int Receiver::set_mode(uint32_t ch, int mode)
     std::lock_guard<std::mutex> g(mu_);
     if (ctl_[ch].mode != mode) am_list_dirty_ = true;
     ctl_[ch].mode = mode;
+    if (!wfm) {  // "Tune only mode": the reference returns before NoiseFilter and AGC (receiver.cpp:968-971): their states stay frozen
+        agc_.set_muted(ch, mode == PEBBLEGPU_DM_NONE);
+        anf_.set_muted(ch, mode == PEBBLEGPU_DM_NONE);
+    }
     return 0;
 }
 
@@ -263,6 +275,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
 {
     std::lock_guard<std::mutex> g(mu_);
     PG_HIP(hipSetDevice(device));
+    if (failed_) return fail(PEBBLEGPU_E_HIP, "an earlier call on this receiver failed half-way (its filter histories no longer match its oscillators): destroy it");
     if (!d_iq || n == 0) return fail(PEBBLEGPU_E_INVALID, "null input or zero samples");
     if (with_chain && (n % superframe != 0 || n / superframe > max_sf))
         return fail(PEBBLEGPU_E_SIZE, "n_samples %llu is not 1..%u super-frames of %llu", (unsigned long long)n, max_sf,
@@ -289,6 +302,17 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (side) {
         PG_HIP(hipStreamWaitEvent(chain_stream_, ev[0], 0));  // fork: the input is ready where the call's start event is
     }
+    // From here on a failing step leaves kernels queued (on the chain stream too) and histories half advanced: whatever the
+    // exit, join the two streams so later work is ordered behind what was queued, and refuse further calls on the handle.
+    struct Guard {
+        Receiver *r; hipEvent_t *ev; hipStream_t cs; bool side, armed;
+        ~Guard()
+        {
+            if (!armed) return;
+            r->failed_ = true;
+            if (side && hipEventRecord(ev[6], cs) == hipSuccess) r->chain_end_ = ev[6];
+        }
+    } guard{this, ev, cs, side, true};
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
         if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
         last_spec_frames = n / nf;
@@ -302,6 +326,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (!with_chain) {
         if (profile_detail) for (int i = 2; i <= 5; i++) PG_HIP(hipEventRecord(ev[i], stream_));
         PG_HIP(hipEventRecord(ev[6], stream_));
+        guard.armed = false;
         return 0;
     }
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
@@ -310,6 +335,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr)) return rc;
     if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
     const long long nd = dec_.out_len();
+    if (zoom_bins) {  // SignalSpectrum::zoomed(m_sampleBuf, numStepSamples), receiver.cpp:884 / :942 (the update timer forced open)
+        if (int rc = zoom_.run(cs, dec_.out().data(), dec_.out().pitch, nd / nf, d_zoom)) return rc;
+        last_zoom_frames = (uint64_t)(nd / nf);
+    }
     if (!wfm) {
         if (int rc = ff_.run(cs, dec_.out(), nd, audio.data(), audio.pitch)) return rc;  // receiver.cpp:950
         if (profile_detail) PG_HIP(hipEventRecord(ev[4], cs));
@@ -323,9 +352,17 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipStreamSynchronize(cs));
         gate_closed = (double)h_gate_->y < squelch_db_;  // m_avgDb < m_squelchDb
     }
-    if (gate_closed) {
-        squelched_calls++;
+    // dmNONE, "Tune only mode, no demod or output" (receiver.cpp:968-971): for the reference's own shape (one channel) the call
+    // ends here like a closed gate -- nothing behind the band-pass runs or changes state, no audio leaves; in a bank the
+    // tune-only channels sit out the noise filter, AGC and demodulators (muted lists) and their audio rows are cleared
+    bool tune_only = false;
+    if (!wfm && !gate_closed) {
+        if (C == 1) tune_only = ctl_[0].mode == PEBBLEGPU_DM_NONE;
+    }
+    if (gate_closed || tune_only) {
+        if (gate_closed) squelched_calls++;
         last_audio_n = 0;
+        gate_closed = true;
         if (profile_detail) { if (wfm) PG_HIP(hipEventRecord(ev[4], cs)); }
     } else if (!wfm) {
         if (int rc = anf_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
@@ -334,6 +371,8 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (int rc = am_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
         if (sam_.C) { if (int rc = sam_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
         if (nfm_.C) { if (int rc = nfm_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
+        for (uint32_t ch = 0; ch < C; ch++)  // clearCPX(m_audioBuf, ...) of the bank's tune-only channels
+            if (ctl_[ch].mode == PEBBLEGPU_DM_NONE) PG_HIP(hipMemsetAsync(audio.data((int)ch), 0, sizeof(float2) * (size_t)nd, cs));
     } else {
         if (profile_detail) PG_HIP(hipEventRecord(ev[4], cs));
         if (int rc = wfmc_.run(cs, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
@@ -361,6 +400,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipEventRecord(ev[6], stream_));
     }
     osc_.advance(n);
+    guard.armed = false;
     return 0;
 }
 

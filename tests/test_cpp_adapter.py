@@ -86,3 +86,16 @@ def test_config1_wav_to_audio_through_cpp_host(exe, tmp_path, oracle_mod, fft, t
     assert got.shape == want.shape and len(want) >= 3 * 2048
     err = np.sqrt(np.mean(np.abs(got - want) ** 2)) / np.sqrt(np.mean(np.abs(want) ** 2))
     assert err <= 1e-5
+
+
+@pytest.mark.gpu
+def test_plain_c_host_and_the_async_contract():
+    """examples/async_contract.c (gcc, no Python wrapper): results read through pebblegpu_memcpy_d2h right behind a queued
+    process call equal the synchronised ones, and an input refill right behind a call does not overtake it."""
+    import __graft_entry__ as g
+    g.build()
+    src, exe_c = os.path.join(ROOT, "examples", "async_contract.c"), os.path.join(ROOT, "examples", "async_contract")
+    lib = os.path.join(ROOT, "pebblesdr_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-L" + lib, "-lpebblegpu", "-Wl,-rpath," + lib, "-lm", "-o", exe_c])
+    r = subprocess.run([exe_c], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

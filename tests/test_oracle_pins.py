@@ -417,3 +417,72 @@ def test_wfm_stereo_pilot_pll_of_the_reference_does_not_hold_lock(oracle_mod):
         assert d.s.err_ave > 1.0                                        # ... the phase detector never settles
         tail = np.concatenate(outs[8:])
         assert np.array_equal(tail.real, tail.imag)                     # mono in both channels
+
+
+def test_uncompensated_bin_power_of_a_full_scale_tone(oracle_mod):
+    """pebblelib/fft.cpp:282-290: "a BlackmanHarris window has a gain factor of 0.36 ... the expected uncompensated power in our
+    1 bin should be 2048 * 0.36 = 737.28".  A full-scale bin-centred tone through the oracle's window and transform: the bin
+    holds N * coherentGain = 2048 * 0.35875 = 734.72 (the comment rounds the gain to 0.36), everything else ~0."""
+    O = oracle_mod
+    n = 2048
+    s = O.Spectrum(2048, n)
+    w = s.window()
+    x = np.exp(2j * np.pi * 200 * (np.arange(n)) / n)
+    X = O.fft(x * w)
+    assert abs(np.abs(X[200]) - 2048 * s.coherent_gain) < 1e-6 * 2048
+    assert abs(np.abs(X[200]) - 737.28) / 737.28 < 4e-3          # the comment's figure, with its rounded 0.36
+    # the (i + 0.5)/N phase of the reference's window leaves e^{j pi k/N}-modulated leakage on the four-term main lobe only
+    assert np.abs(np.delete(X, [197, 198, 199, 200, 201, 202, 203])).max() < 1e-3 * np.abs(X[200])
+
+
+def test_window_coherent_gains_should_be_comments():
+    """pebblelib/windowfunction.cpp:74-233 annotates eight windows with the coherent gain they "SB" (should be): 1, 0.50, 0.67,
+    0.69, 0.50, 0.54, 0.42, 0.36.  Restating the loops as written shows which of those the code produces.  RECTANGULAR and
+    BLACKMANHARRIS (the only one on the receive path, signalspectrum.cpp:58) sum the whole window and give their figure;
+    the symmetric windows sum i = 0 .. N/2 only (`i <= midn`) and divide by N, i.e. HALF the annotated gain; WELCH's argument
+    is an integer division that is zero over that range (window = 1 -> 0.50), PARZEN's triangle halves to 0.25, and
+    BLACKMAN's formula reads coherentGain before it is set.  Only the two full-sum windows are known answers of the code."""
+    n = 2048
+    midn, midp1, midm1 = n // 2, (n + 1) // 2, (n - 1) // 2
+    two_pi = np.float32(2 * np.pi)
+    freq = np.float32(two_pi / np.float32(n))
+    i = np.arange(midn + 1)
+    angle = np.cumsum(np.concatenate([[np.float32(0)], np.full(midn, freq, dtype=np.float32)])).astype(np.float32)  # angle += freq
+    rect = np.ones(n).sum() / n                                                        # :68-74
+    hann = (0.5 - 0.5 * np.cos(angle.astype(np.float64))).sum() / n                    # :79-85
+    welch = (1.0 - np.sqrt(np.trunc((i - midm1) / midp1).clip(0).astype(np.float32))).sum() / n   # :91-97, int / int
+    parzen = (1.0 - np.abs((i - midm1).astype(np.float32) / midp1)).sum() / n          # :103-109
+    rate = np.float32(1.0 / midn)
+    bart = np.cumsum(np.concatenate([[np.float32(0)], np.full(midn, rate, dtype=np.float32)])).astype(np.float64).sum() / n  # :115-121
+    hamm = (0.54 - 0.46 * np.cos(angle.astype(np.float64))).sum() / n                  # :129-135
+    a = [np.float32(v) for v in (0.35875, 0.48829, 0.14128, 0.01168)]                  # :214-233
+    k = (np.arange(n) + 0.5) / n
+    bh = (a[0] - a[1] * np.cos(float(two_pi) * k) + a[2] * np.cos(2.0 * float(two_pi) * k) - a[3] * np.cos(3.0 * float(two_pi) * k)).sum() / n
+    assert rect == 1.0                                    # SB 1
+    assert round(bh, 2) == 0.36 and abs(bh - 0.35875) < 1e-6   # SB 0.36
+    assert abs(hann - 0.50 / 2) < 1e-3                    # SB 0.50: the loop covers half the window
+    assert abs(hamm - 0.54 / 2) < 1e-3                    # SB 0.54
+    assert abs(bart - 0.50 / 2) < 1e-3                    # SB 0.50
+    assert abs(welch - 0.50) < 1e-3                       # SB 0.67: the square root's argument is an integer quotient, 0 here
+    assert abs(parzen - 0.25) < 1e-3                      # SB 0.69
+
+
+@pytest.mark.parametrize("amp,n", [(1.0, 2048), (1.0, 4096), (0.5, 4096)])
+def test_noise_floor_formula(oracle_mod, amp, n):
+    """application/signalstrength.cpp:124-131: "Expected FFT powerDb = 10*log10(Noise power / Number FFT bins)", tabulated as
+    1.0 / 2048 -> -33.11 dB, 1.0 / 4096 -> -36.12 dB, 0.25 / 4096 -> -42.13 dB.  With the window off (gain 1) and one bin per
+    sample the oracle's normalisation (|X| / N, fft.cpp:347-355) gives E[power per bin] = P / N exactly; fftSpectrum
+    reports the dB of the two-frame AVERAGE AMPLITUDE, whose square for Rayleigh bins is (1 + pi/4)/2 of the power (-0.49 dB)."""
+    O = oracle_mod
+    want = {(1.0, 2048): -33.11, (1.0, 4096): -36.12, (0.5, 4096): -42.13}[(amp, n)]
+    assert abs(10 * np.log10(amp * amp / n) - want) < 0.02   # the table rounds (its last row is 0.014 dB off its own formula)
+    rng = np.random.default_rng(7)
+    s = O.Spectrum(n, n, window=False)
+    acc = []
+    for f in range(12):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * (amp / np.sqrt(2.0)) * 0.2   # power (0.2 amp)^2, |x| < 0.9
+        db = s.process(x)
+        if f:
+            acc.append(np.mean(10 ** (db / 10)))
+    got = 10 * np.log10(np.mean(acc)) - 20 * np.log10(0.2)
+    assert abs(got - (want + 10 * np.log10((1 + np.pi / 4) / 2))) < 0.1

@@ -434,8 +434,10 @@ def test_independent_streams_and_retune(gpu_lib, oracle_mod):
             r = np.concatenate([o[0] for o in outs])
             rs = np.array([o[1] for o in outs])
             if call == 2 and c == 0:
-                # dmNONE: the reference clears m_audioBuf and returns (receiver.cpp:968-971); the bank leaves the
-                # band-passed samples in place and the host discards them -- both produce no audio downstream
+                # dmNONE: the reference clears m_audioBuf and returns before the audio callback (receiver.cpp:968-971):
+                # nothing comes out of the oracle, and the bank's row for that channel is cleared
+                assert len(r) == 0 and not a[c].any()
+                assert db_err(s[c], rs) <= TOL_DB  # the spectrum is taken before the branch
                 continue
             assert rel_rms(a[c], r) <= TOL
             assert db_err(s[c], rs) <= TOL_DB
@@ -1199,3 +1201,151 @@ def test_lifecycle_and_back_to_back_calls(gpu_lib, oracle_mod):
     with pytest.raises(P.PebbleGpuError):
         rx.process_device(buf.ptr, 0)
 
+
+
+def test_bench_geometry_256_superframes_against_the_oracle(gpu_lib, oracle_mod):
+    """bench.py's own call shape: configs[1] with 256 super-frames in ONE call, which makes the 8192-bin transform walk
+    chains of 32 frames (two chains per 1024-item workgroup, the halves three barrier intervals apart) and the WFM chain
+    run its long-call paths.  Against the oracle: the first three audio frames and the last one, and the spectra at both
+    ends of the call and on both sides of three chain boundaries (frames 31|32, 32|33, 8191|8192|8193, 16351|16352);
+    then the same input as two calls of 128: bit for bit in the spectrum."""
+    import pebblesdr_amd as P
+    fs, n, k = 20_000_000, 2048, 256
+    rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=k)
+    rx.set_mixer(0, 1.0e6)
+    sf = rx.superframe
+    N = k * sf
+    t = np.arange(N, dtype=np.float64) / fs
+    x = 0.5 * np.exp(1j * (2 * np.pi * 1.0e6 * t + 75.0 * np.sin(2 * np.pi * 1000 * t)))
+    del t
+    x += lcg_noise(N, 11, 1e-2)
+    x = ((np.round(x.real * 128) + 1j * np.round(x.imag * 128)) / 128.0).astype(np.complex64)
+    A, S = rx.process(x)
+    assert S.shape == (1, N // n, 8192) and A.shape == (1, N // 64)
+    # spectra: frame f averages with frame f - 1, so the oracle transforms the pair (its first output is discarded)
+    frames = [1, 2, 31, 32, 33, 8191, 8192, 8193, 16351, 16352, N // n - 1]
+    for f in frames:
+        sp = oracle_mod.Spectrum(8192, 2048)
+        sp.process(x[(f - 1) * n:f * n].astype(np.complex128))
+        r = sp.process(x[f * n:(f + 1) * n].astype(np.complex128))
+        assert db_err(S[0, f], r) <= TOL_DB, "frame %d" % f
+    # audio: the whole stream through the oracle chain (8192-sample decimator frames, see test_config2_wfm_with_spectrum)
+    mix = oracle_mod.Mixer(fs); mix.set_frequency(1.0e6)
+    dec = oracle_mod.Decimator(fs, 200000)
+    dem = oracle_mod.DemodWFM(312500)
+    z = np.concatenate([dec.process(mix.process(x[i:i + 8192].astype(np.complex128))) for i in range(0, N, 8192)])
+    ra = np.concatenate([dem.process(z[i:i + 2048]) for i in range(0, len(z), 2048)])
+    for fr in (0, 1, 2, 127, 128, k - 1):
+        assert rel_rms(A[0, fr * 2048:(fr + 1) * 2048], ra[fr * 2048:(fr + 1) * 2048]) <= TOL, "audio frame %d" % fr
+    # call splitting at this size
+    rx2 = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=k)
+    rx2.set_mixer(0, 1.0e6)
+    h = N // 2
+    (A1, S1), (A2, S2) = rx2.process(x[:h]), rx2.process(x[h:])
+    assert np.array_equal(np.concatenate([S1, S2], axis=1), S)
+    assert np.abs(np.concatenate([A1, A2], axis=1) - A).max() <= 1e-6
+
+
+def test_empty_pass_band_meets_the_input_relative_bar(gpu_lib, oracle_mod):
+    """The device stores samples in fp32, so its error is ~1e-7 of the INPUT's RMS; a band-pass that rejects the input's
+    energy leaves an output so small that the same absolute error exceeds 1e-5 of the OUTPUT.  The bar is therefore two-sided:
+    rel-RMS <= 1e-5 of the output, OR absolute RMS error <= 2e-7 of the input RMS.  Here the pass-band (USB 300-3000 Hz) holds
+    nothing but the noise floor 80 dB under an out-of-band tone: the output-relative figure is allowed to miss, the
+    input-relative one is not.  A second channel has its tone in band and must meet the output-relative bar."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    rx = P.ReceiverBank(fs, 2, True, False, 0, max_superframes=3)
+    fc = [52e3, 80e3]
+    refs = []
+    for c in range(2):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fc[c]); rx.set_bandpass(c, 300, 3000)
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fc[c]); r.set_filter(300, 3000)
+        refs.append(r)
+    sf = rx.superframe
+    N = 3 * sf
+    # one tone: 15 kHz above channel 0's carrier (far outside its 300-3000 Hz pass-band), 1.5 kHz above channel 1's (inside)
+    x = tones(fs, N, [(0.5, 52e3 + 15e3), (0.5, 80e3 + 1.5e3)]) + lcg_noise(N, 3, 1e-5)
+    g = rx.process(x)[0]
+    in_rms = float(np.sqrt(np.mean(np.abs(x) ** 2)))
+    for c in range(2):
+        r = np.concatenate([refs[c].process(x[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(N // n)])
+        assert r.shape == g[c].shape
+        for fr in range(3):
+            sl = slice(fr * 2048, (fr + 1) * 2048)
+            rel_out = rel_rms(g[c][sl], r[sl])
+            abs_in = float(np.sqrt(np.mean(np.abs(g[c][sl] - r[sl]) ** 2))) / in_rms
+            assert rel_out <= TOL or abs_in <= 2e-7, "channel %d frame %d: %.2e of output, %.2e of input" % (c, fr, rel_out, abs_in)
+            if c == 1:
+                assert rel_out <= TOL
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_tune_only_mode_freezes_what_lies_behind_it(gpu_lib, oracle_mod, C):
+    """dmNONE, "Tune only mode, no demod or output" (receiver.cpp:968-971): the call returns behind the band-pass -- no audio,
+    and noise filter, AGC, demodulator and resampler keep the state the last demodulated super-frame left.  AM with a fast
+    AGC (whose state a wrongly processed super-frame would visibly move): mode AM, AM, NONE, NONE, AM, AM against the
+    oracle; C = 1 is the reference's own shape (the call reports zero samples), C = 3 a bank whose channel 1 alone goes
+    tune-only (its row is cleared while the others keep demodulating)."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    fcs = [100e3, 250e3, -300e3][:C]
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    refs = []
+    for c, fc in enumerate(fcs):
+        rx.set_mode(c, P.DM_AM); rx.set_mixer(c, fc); rx.set_bandpass(c, -5000, 5000); rx.set_agc(c, 1, 20)
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.AM); r.set_mixer(fc); r.set_filter(-5000, 5000); r.set_agc(1, 20)
+        refs.append(r)
+    sf = rx.superframe
+    pattern = ["AM", "AM", "NONE", "NONE", "AM", "AM"]
+    N = len(pattern) * sf
+    t = np.arange(N) / fs
+    x = sum(0.1 * (1 + 0.5 * np.cos(2 * np.pi * (600 + 150 * c) * t)) * (1 + 0.8 * np.sin(2 * np.pi * 3.0 * t)) * np.exp(2j * np.pi * fc * t)
+            for c, fc in enumerate(fcs)) + lcg_noise(N, 9, 1e-4)
+    who = 0 if C == 1 else 1   # the channel that goes tune-only
+    for k, m in enumerate(pattern):
+        if k == 0 or pattern[k - 1] != m:
+            rx.set_mode(who, P.DM_AM if m == "AM" else P.DM_NONE)
+            refs[who].set_mode(oracle_mod.AM if m == "AM" else oracle_mod.NONE)
+        g = rx.process(x[k * sf:(k + 1) * sf])[0]
+        for c in range(C):
+            r = np.concatenate([refs[c].process(x[k * sf + f * n:k * sf + (f + 1) * n], want_spectrum=False)[0] for f in range(sf // n)])
+            if c == who and m == "NONE":
+                assert len(r) == 0
+                assert (g.shape[1] == 0) if C == 1 else (g.shape[1] == 2048 and not g[c].any())
+            else:
+                assert g[c].shape == r.shape
+                # the fast AGC multiplies the fp32 input error by its gain slope: 2e-5 (see test_squelch_gate_*), not 1e-5
+                assert rel_rms(g[c], r) <= 2e-5, "super-frame %d channel %d" % (k, c)
+
+
+@pytest.mark.parametrize("wfm", [False, True])
+def test_zoomed_spectrum_of_the_decimated_frames(gpu_lib, oracle_mod, wfm):
+    """SignalSpectrum::zoomed (signalspectrum.cpp:89-113, called at receiver.cpp:884 / :942): fftSpectrum with the hi-res bin
+    count (settings.cpp:61: 2048) and a BlackmanHarris window over framesPerBuffer samples, of m_sampleBuf -- every frame at the
+    demodulator rate, behind the gain restore on the narrow branch.  Two calls (the previous-frame average carries over)."""
+    import pebblesdr_amd as P
+    fs, n = 2048000, 2048
+    C = 1 if wfm else 2
+    fcs = [150e3, -320e3][:C]
+    rx = P.ReceiverBank(fs, C, True, wfm, 0, max_superframes=3, hires_bins=2048)
+    for c in range(C):
+        rx.set_mixer(c, fcs[c])
+        if not wfm:
+            rx.set_mode(c, P.DM_USB); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    N = 5 * sf
+    x = tones(fs, N, [(0.2, fcs[0] + 1234.5), (0.02, fcs[0] - 7000.0)] + ([(0.1, fcs[1] + 2500.0)] if C > 1 else [])) + lcg_noise(N, 4, 1e-3)
+    Z = np.concatenate([(rx.process(x[lo:hi]), rx.zoom_spectrum())[1] for lo, hi in ((0, 2 * sf), (2 * sf, 5 * sf))], axis=1)
+    stages = sum(int(np.log2(st)) for _, st in rx.chain())
+    gain = 1.0 if wfm else 10 ** (2 * stages / 20.0)
+    for c in range(C):
+        mix = oracle_mod.Mixer(fs); mix.set_frequency(fcs[c])
+        dec = oracle_mod.Decimator(fs, 200000 if wfm else 30000)
+        z = np.concatenate([dec.process(mix.process(x[i:i + 8192])) for i in range(0, N, 8192)]) * gain
+        sp = oracle_mod.Spectrum(2048, 2048)
+        ref = np.array([sp.process(z[f * n:(f + 1) * n]) for f in range(len(z) // n)])
+        assert Z[c].shape == ref.shape
+        for f in range(1, len(ref)):
+            assert db_err(Z[c][f], ref[f]) <= TOL_DB, "channel %d frame %d" % (c, f)
