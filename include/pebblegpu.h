@@ -208,14 +208,17 @@ int pebblegpu_set_noise_filter(pebblegpu_receiver *rx, uint32_t channel, int on)
 int pebblegpu_receiver_enable_signal_strength(pebblegpu_receiver *rx, int on);
 const void *pebblegpu_receiver_signal_strength(const pebblegpu_receiver *rx, uint64_t *frames, uint64_t *pitch_frames);
 /* Squelch (Receiver::squelchChanged, receiver.cpp:704-707; the gate at :893-897 for WFM and :962-965 otherwise).  Once a
- * super-frame has been mixed, decimated and (narrow chains) band-passed, avgDb of the most recent unprocessed spectrum
- * is compared with squelch_db: below it the call ends there -- noise filter, AGC, demodulator and resampler are not run
- * and keep their state, and the call reports zero audio samples (pebblegpu_receiver_audio's n, process_iq's n_audio),
- * exactly the reference's early return.  -120 (DB::minDb, the reference's default) never closes the gate.  The decision
- * costs one 16-byte read-back and a stream synchronisation per call, so it is made only while a threshold above -120
- * is set.  Defined for the reference's own shape: a one-channel receiver called one super-frame at a time
- * (PEBBLEGPU_E_UNSUPPORTED otherwise: a bank would need per-channel stream lengths behind the gate).  Turns the S-meter
- * on; needs spectrum_bins != 0 and a spectrum in the same or an earlier call. */
+ * super-frame has been mixed, decimated and (narrow chains) band-passed, avgDb of the unprocessed spectrum of its last raw frame
+ * is compared with squelch_db: below it the channel's processing ends there -- noise filter, AGC, demodulator and resampler
+ * are not run and keep their state -- exactly the reference's early return.  -120 (DB::minDb, the reference's default) never
+ * closes the gate.  Turns the S-meter on; needs spectrum_bins != 0.
+ *   - the reference's own shape, one channel called one super-frame at a time (narrow or WFM): the call reports ZERO audio
+ *     samples (pebblegpu_receiver_audio's n, process_iq's n_audio); the decision costs one 16-byte read-back and a stream
+ *     synchronisation per call, made only while a threshold above -120 is set;
+ *   - a narrow bank, or calls of several super-frames: one threshold per channel, the decision per (channel, super-frame) made on
+ *     the device from the same call's spectra (no read-back, no synchronisation); a closed (channel, super-frame) reads as
+ *     silence in the bank's audio rows (the count is common to all channels), and with audio_rate set the resampler sees that
+ *     silence (a single Receiver's resampler would have slept).  WFM banks: PEBBLEGPU_E_UNSUPPORTED. */
 int pebblegpu_set_squelch(pebblegpu_receiver *rx, uint32_t channel, double squelch_db);
 /* waits until every process call made on this handle has finished: its outputs are then valid and its input may be reused */
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);

@@ -515,7 +515,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         if (wide) {  // the peeled stride->=8 stage: every output reads its own taps-long window straight from buf0
             len1 = len0 / wide_stride;
             launch(k_fir_dec, dim3(cdiv(len1, 256), C), dim3(256), s, (const float2 *)buf0.data(), buf0.pitch, buf1.data(), buf1.pitch, len1, wide_stride,
-                   (const float *)d_wide_taps, (const float *)nullptr, 0, (const int *)nullptr, wide_taps, 1.0f, 0, (const int *)nullptr);
+                   (const float *)d_wide_taps, (const float *)nullptr, 0, (const int *)nullptr, wide_taps, 1.0f, 0, (const int *)nullptr, Gate{nullptr, 0, 0});
             src = &buf1;
         }
     }
@@ -675,7 +675,7 @@ int AmCore::set_list(hipStream_t s, const std::vector<int> &am_channels)
     }
     return 0;
 }
-int AmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
+int AmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n, Gate gate)
 {
     if (list.empty()) return 0;
     if (n > tmp.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
@@ -685,10 +685,10 @@ int AmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out
     // One workgroup per channel walks the call sequentially (the 0.9999 pole forbids a warm-up), so it may read
     // and write the same state slot; a channel that leaves AM keeps its stale state like the idle Demod_AM object.
     launch(k_iir_scan<2, 1>, dim3(1, na), dim3(64), s, in, in_pitch, tmp.data(), tmp.pitch, n, scan, (const double *)d_state, d_state,
-           (int)nsub, -1, (const int *)d_list);
+           (int)nsub, -1, (const int *)d_list, gate);
     launch(k_fir_dec, dim3(cdiv(n, 256), na), dim3(256), s, (const float2 *)tmp.data(), tmp.pitch, out, out_pitch, n, 1,
-           (const float *)d_taps, (const float *)nullptr, (int)kMaxTaps, (const int *)d_ntaps, 0, 1.0f, 0, (const int *)d_list);
-    launch(k_save_tail, dim3(cdiv(tmp.hist, 256), na), dim3(256), s, tmp.data(), tmp.pitch, n, tmp.hist, (const int *)d_list);
+           (const float *)d_taps, (const float *)nullptr, (int)kMaxTaps, (const int *)d_ntaps, 0, 1.0f, 0, (const int *)d_list, gate);
+    launch(k_save_tail, dim3(cdiv(tmp.hist, 256), na), dim3(256), s, tmp.data(), tmp.pitch, n, tmp.hist, (const int *)d_list, gate);
     PG_HIP(hipGetLastError());
     return 0;
 }
@@ -761,19 +761,19 @@ int PllCore::set_list(hipStream_t s, const std::vector<int> &channels)
     }
     return 0;
 }
-int PllCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
+int PllCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n, Gate gate)
 {
     if (list.empty()) return 0;
     if (n > tmp.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
     const unsigned nl = (unsigned)list.size();
     launch(k_pll_demod, dim3(cdiv(nl, 64)), dim3(64), s, in, in_pitch, tmp.data(), tmp.pitch, n, pp, d_state, (const int *)d_list,
-           (int)nl);
+           (int)nl, gate);
     launch(k_fir_dec, dim3(cdiv(n, 256), nl), dim3(256), s, (const float2 *)tmp.data(), tmp.pitch, out, out_pitch, n, 1, (const float *)d_taps_i,
-           (const float *)d_taps_q, 0, (const int *)nullptr, ntaps, 1.0f, mode == 1 ? 1 : 0, (const int *)d_list);
-    std::vector<TailJob> jobs;
-    // listed channels only would need a list-aware tail kernel; refreshing every row is harmless (idle rows keep zeros)
-    jobs.push_back(TailJob{tmp.data(), tmp.pitch, n, tmp.hist, 0, nullptr, 0});
-    return run_save_tails(s, jobs, C);
+           (const float *)d_taps_q, 0, (const int *)nullptr, ntaps, 1.0f, mode == 1 ? 1 : 0, (const int *)d_list, gate);
+    // the listed channels' FIR history (a gated channel keeps its own)
+    launch(k_save_tail, dim3(cdiv(tmp.hist, 256), nl), dim3(256), s, tmp.data(), tmp.pitch, n, tmp.hist, (const int *)d_list, gate);
+    PG_HIP(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -878,14 +878,14 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
     // slow poles: one workgroup per channel walks the call sequentially with the exact carried state
     if (lp_on)
         launch(k_iir_scan<0, 1>, dim3(1, C), dim3(64), s, in, in_pitch, a.data(), a.pitch, n, lp, (const double *)d_lp_state[0], d_lp_state[0],
-               (int)nsub, -1, (const int *)nullptr);
+               (int)nsub, -1, (const int *)nullptr, Gate{nullptr, 0, 0});
     else
         launch(k_copy, dim3(cdiv(n, 256), C), dim3(256), s, in, in_pitch, a.data(), a.pitch, n);
     launch(k_discrim, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)a.data(), a.pitch, b.data(), b.pitch, n, 0.25f);  // FMDEMOD_GAIN
     launch(k_fir_dec, dim3(cdiv(n, 256), C), dim3(256), s, (const float2 *)b.data(), b.pitch, c.data(), c.pitch, n, 1, (const float *)d_taps,
-           (const float *)nullptr, 0, (const int *)nullptr, ntaps, 1.0f, 0, (const int *)nullptr);
+           (const float *)nullptr, 0, (const int *)nullptr, ntaps, 1.0f, 0, (const int *)nullptr, Gate{nullptr, 0, 0});
     launch(k_iir_scan<1, 2>, dim3(1, C), dim3(64), s, (const float2 *)c.data(), c.pitch, out, out_pitch, n, dn, (const double *)d_dn_state[0],
-           d_dn_state[0], (int)nsub, -1, (const int *)nullptr);
+           d_dn_state[0], (int)nsub, -1, (const int *)nullptr, Gate{nullptr, 0, 0});
     PG_HIP(hipGetLastError());
     return 0;
 }
@@ -897,6 +897,20 @@ void WfmCore::tail_jobs(std::vector<TailJob> &jobs) const
     }
     jobs.push_back(TailJob{a.data(), a.pitch, last_n, a.hist, 0, nullptr, 0});
     jobs.push_back(TailJob{b.data(), b.pitch, last_n, b.hist, 0, nullptr, 0});
+}
+
+int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
+                  int stride, uint32_t channels)
+{
+    launch(k_gate_eval, dim3((unsigned)((channels * (unsigned)k + 255) / 256)), dim3(256), s, d_smeter, smeter_pitch, frames_per_sf, k, d_squelch, d_gate, stride, (int)channels);
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+int run_gate_zero(hipStream_t s, float2 *audio, long long pitch, long long spf, const unsigned char *d_gate, int stride, uint32_t channels, int k)
+{
+    launch(k_gate_zero, dim3((unsigned)((spf + 1023) / 1024), channels, (unsigned)k), dim3(256), s, audio, pitch, spf, d_gate, stride);
+    PG_HIP(hipGetLastError());
+    return 0;
 }
 
 int run_signal_strength(hipStream_t s, const float *d_spec, long long stream_pitch, int bins, long long n_frames, const SmBins *d_bins,
@@ -1000,10 +1014,10 @@ int AgcCore::apply(hipStream_t s)
     list_dirty = false;
     return 0;
 }
-int AgcCore::run(hipStream_t s, float2 *buf, long long pitch, long long n)
+int AgcCore::run(hipStream_t s, float2 *buf, long long pitch, long long n, Gate gate)
 {
     if (list.empty()) return 0;  // AGC_OFF with unit manual gain: out = 1.0 * in
-    launch(k_agc, dim3(cdiv((long long)list.size(), 64)), dim3(64), s, buf, pitch, n, d_state, (const int *)d_list, (int)list.size());
+    launch(k_agc, dim3(cdiv((long long)list.size(), 64)), dim3(64), s, buf, pitch, n, d_state, (const int *)d_list, (int)list.size(), gate);
     PG_HIP(hipGetLastError());
     return 0;
 }
@@ -1093,7 +1107,7 @@ int ConditionCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lo
     if (!dc_list.empty()) {  // DCRemoval::process: CIir high-pass 10 Hz, exact carried state (its pole sits at 1 - 3e-6 .. 3e-5)
         const long long nsub = (n + kSub - 1) / kSub;
         launch(k_iir_scan<0, 1>, dim3(1, (unsigned)dc_list.size()), dim3(64), s, (const float2 *)d_buf, cap, d_buf, cap, n, dc, (const double *)d_dc_state,
-               d_dc_state, (int)nsub, -1, (const int *)d_dc_list);
+               d_dc_state, (int)nsub, -1, (const int *)d_dc_list, Gate{nullptr, 0, 0});
     }
     if (iq_any) launch(k_iq_balance, dim3(cdiv(n / nf, 64), S), dim3(64), s, d_buf, cap, (int)nf, n / nf, (const double2 *)d_iq);
     if (nb_any) launch(k_noise_blank, dim3(cdiv(S, 64)), dim3(64), s, d_buf, cap, n, d_nb, (int)S);
@@ -1138,10 +1152,10 @@ int AnfCore::apply(hipStream_t s)
     dirty = false;
     return 0;
 }
-int AnfCore::run(hipStream_t s, float2 *buf, long long pitch, long long n)
+int AnfCore::run(hipStream_t s, float2 *buf, long long pitch, long long n, Gate gate)
 {
     if (list.empty()) return 0;
-    launch(k_anf, dim3((unsigned)list.size()), dim3(64), s, buf, pitch, n, d_state, (const int *)d_list);
+    launch(k_anf, dim3((unsigned)list.size()), dim3(64), s, buf, pitch, n, d_state, (const int *)d_list, gate);
     PG_HIP(hipGetLastError());
     return 0;
 }

@@ -81,12 +81,13 @@ static __global__ __launch_bounds__(64) void k_iir_scan(const float2 *__restrict
                                                   float2 *__restrict__ out, long long out_pitch, long long n,
                                                   ScanParams<NSEC> sp, const double *__restrict__ state_in,
                                                   double *__restrict__ state_out, int sub_per_block, int warm_sub,
-                                                  const int *__restrict__ chan_list)
+                                                  const int *__restrict__ chan_list, Gate gate)
 {
     __shared__ float re[kSub + kSub / kSeg + 1];
     __shared__ float im[kSub + kSub / kSeg + 1];
     const int lane = threadIdx.x;
     const int c = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    if (gate.closed(c)) return;  // workgroup-uniform
     const long long nsub = (n + kSub - 1) / kSub;
     const long long first_out = (long long)blockIdx.x * sub_per_block;
     long long last = first_out + sub_per_block;
@@ -282,11 +283,12 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
 // CFir that follows is k_fir_dec.
 static __global__ __launch_bounds__(64) void k_pll_demod(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ out,
                                                          long long out_pitch, long long n, PllParams pp, PllState *__restrict__ st,
-                                                         const int *__restrict__ chan_list, int nlist)
+                                                         const int *__restrict__ chan_list, int nlist, Gate gate)
 {
     const int li = blockIdx.x * 64 + threadIdx.x;
     if (li >= nlist) return;
     const int c = chan_list ? chan_list[li] : li;
+    if (gate.closed(c)) return;
     const float2 *x = in + (long long)c * in_pitch;
     float2 *y = out + (long long)c * out_pitch;
     PllState s = st[c];
@@ -368,11 +370,12 @@ struct AgcState {        // per channel, device resident
 };
 
 static __global__ __launch_bounds__(64) void k_agc(float2 *__restrict__ buf, long long pitch, long long n, AgcState *__restrict__ st,
-                                                   const int *__restrict__ chan_list, int nlist)
+                                                   const int *__restrict__ chan_list, int nlist, Gate gate)
 {
     const int li = blockIdx.x * 64 + threadIdx.x;
     if (li >= nlist) return;
     const int c = chan_list[li];
+    if (gate.closed(c)) return;
     float2 *x = buf + (long long)c * pitch;
     AgcState *a = st + c;
     if (a->mode == 0) {  // manual gain, agc.cpp:86-95
@@ -555,9 +558,10 @@ struct AnfState {
     int head, last, pad_[2];
 };
 static __global__ __launch_bounds__(64) void k_anf(float2 *__restrict__ buf, long long pitch, long long n, AnfState *__restrict__ st,
-                                                   const int *__restrict__ chan_list)
+                                                   const int *__restrict__ chan_list, Gate gate)
 {
     const int c = chan_list[blockIdx.x], lane = threadIdx.x;
+    if (gate.closed(c)) return;  // wave-uniform
     float2 *x = buf + (long long)c * pitch;
     AnfState *a = st + c;
     const bool tap = lane < kAnfTaps;

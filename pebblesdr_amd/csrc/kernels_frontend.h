@@ -643,10 +643,11 @@ static __global__ __launch_bounds__(256) void k_fir_dec(const float2 *__restrict
                                                   float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                   int stride, const float *__restrict__ taps, const float *__restrict__ taps_q,
                                                   int taps_pitch, const int *__restrict__ ntaps_per_chan, int ntaps_all,
-                                                  float gain, int sideband_mix, const int *__restrict__ chan_list)
+                                                  float gain, int sideband_mix, const int *__restrict__ chan_list, Gate gate)
 {
     __shared__ float hi[kMaxTaps], hq[kMaxTaps];
     const int c = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    if (gate.closed(c)) return;  // workgroup-uniform
     const int T = ntaps_per_chan ? ntaps_per_chan[c] : ntaps_all;
     if (threadIdx.x < kMaxTaps) {
         const int p = threadIdx.x;
@@ -672,9 +673,10 @@ static __global__ __launch_bounds__(256) void k_fir_dec(const float2 *__restrict
 // Copy the last `hist` samples of each channel's data into its head-room: buf[c][-hist + j] = buf[c][n - hist + j].
 // Requires n >= hist (true for every buffer: calls are whole super-frames).  grid (ceil(hist/256), C).
 static __global__ __launch_bounds__(256) void k_save_tail(float2 *__restrict__ data, long long pitch, long long n, int hist,
-                                                    const int *__restrict__ chan_list)
+                                                    const int *__restrict__ chan_list, Gate gate)
 {
     const int c = chan_list ? chan_list[blockIdx.y] : (int)blockIdx.y;
+    if (gate.closed(c)) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= hist) return;
     float2 *b = data + (long long)c * pitch;
@@ -737,6 +739,25 @@ static __global__ __launch_bounds__(256) void k_probe_copy16(const float4 *__res
 static __global__ __launch_bounds__(256) void k_probe_copy8(const float2 *__restrict__ src, float2 *__restrict__ dst, long long n)
 {
     probe_copy_body(src, dst, n);
+}
+
+// The per-channel squelch of a bank.  k_gate_eval: open[c][j] = avgDb of the super-frame's last raw frame >= the channel's threshold
+// (m_avgDb < m_squelchDb closes, receiver.cpp:962-965); k_gate_zero clears the audio of the closed (channel, super-frame) pairs --
+// what a host sees where the reference would have delivered nothing.
+static __global__ __launch_bounds__(256) void k_gate_eval(const float4 *__restrict__ smeter, long long smeter_pitch, int frames_per_sf, int k,
+                                                          const float *__restrict__ squelch_db, unsigned char *__restrict__ open, int stride, int n_chan)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_chan * k) return;
+    const int c = i / k, j = i % k;
+    open[(long long)c * stride + j] = smeter[(long long)c * smeter_pitch + (long long)(j + 1) * frames_per_sf - 1].y < squelch_db[c] ? 0 : 1;
+}
+static __global__ __launch_bounds__(256) void k_gate_zero(float2 *__restrict__ audio, long long pitch, long long spf, const unsigned char *__restrict__ open, int stride)
+{
+    const int c = blockIdx.y, j = blockIdx.z;
+    if (open[(long long)c * stride + j]) return;
+    float2 *a = audio + (long long)c * pitch + (long long)j * spf;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < spf; i += (long long)gridDim.x * 256) a[i] = make_float2(0.f, 0.f);
 }
 
 // All history tails of a call in one launch: buf[c][-hist + j] = buf[c][n - hist + j], j < hist, for every buffer.

@@ -91,6 +91,15 @@ struct TailJobs {
     TailJob job[kMaxTailJobs];
 };
 
+// Per-channel squelch gate of a bank (receiver.cpp:959-965 per channel): open[c * stride + j] != 0 <=> channel c's super-frame j of
+// this call passes.  The kernels behind the band-pass take one super-frame j at a time and leave a closed channel alone
+// (no output, no state change).  open == nullptr: no gate.
+struct Gate {
+    const unsigned char *open;
+    int stride, j;
+    __host__ __device__ bool closed(int c) const { return open != nullptr && open[(long long)c * stride + j] == 0; }
+};
+
 // fdEstimate's bin windows for one channel: noise [nlo, nhi] around the band-pass [lo, hi]; stream = which spectrum it reads
 struct SmBins { int nlo, lo, hi, nhi, bp_bins, stream, pad_[2]; };
 

@@ -38,6 +38,9 @@ int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
 int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait);
+int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
+                  int stride, uint32_t channels);
+int run_gate_zero(hipStream_t s, float2 *audio, long long pitch, long long spf, const unsigned char *d_gate, int stride, uint32_t channels, int k);
 int run_signal_strength(hipStream_t s, const float *d_spec, long long stream_pitch, int bins, long long n_frames, const SmBins *d_bins,
                         float4 *d_out, long long out_pitch, uint32_t channels);
 
@@ -140,7 +143,7 @@ struct AmCore {
     int set_bandwidth(hipStream_t s, uint32_t ch, double bw);   // Demod_AM::setBandwidth, demod_am.cpp:17-21
     int set_list(hipStream_t s, const std::vector<int> &am_channels);
     // in/out rows may be the same buffer (the scan reads `in`, the FIR writes `out`)
-    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n, Gate gate = Gate{nullptr, 0, 0});
 };
 
 // ---- Demod_NFM / Demod_SAM (PLL demodulators) ----
@@ -157,7 +160,7 @@ struct PllCore {
     int init(uint32_t channels, double demod_rate, long long max_n, int which);
     void release();
     int set_list(hipStream_t s, const std::vector<int> &channels);
-    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n, Gate gate = Gate{nullptr, 0, 0});
 };
 
 // ---- Demod_WFM mono ----
@@ -201,7 +204,7 @@ struct AgcCore {
     std::vector<char> muted;        // channels the owner keeps out of the list (dmNONE: the reference returns before the AGC)
     void set_muted(uint32_t ch, bool m) { if (muted.size() != C) muted.assign(C, 0); if ((muted[ch] != 0) != m) { muted[ch] = m; list_dirty = true; } }
     int apply(hipStream_t s);                                // upload changed parameters and the channel list
-    int run(hipStream_t s, float2 *buf, long long pitch, long long n);
+    int run(hipStream_t s, float2 *buf, long long pitch, long long n, Gate gate = Gate{nullptr, 0, 0});
     bool list_dirty = false;
 };
 
@@ -240,7 +243,7 @@ struct AnfCore {
     void release();
     int set(uint32_t ch, bool enable);
     int apply(hipStream_t s);
-    int run(hipStream_t s, float2 *buf, long long pitch, long long n);
+    int run(hipStream_t s, float2 *buf, long long pitch, long long n, Gate gate = Gate{nullptr, 0, 0});
 };
 
 // ---- CFractResampler (complex), pebblelib/fractresampler.cpp ----
@@ -329,7 +332,12 @@ public:
     SmBins *d_sm_bins = nullptr;
     long long smeter_pitch = 0;
     int enable_smeter(bool on);
-    double squelch_db_ = -120.0;      // DB::minDb: the gate never closes (receiverwidget.cpp:82)
+    double squelch_db_ = -120.0;      // DB::minDb: the gate never closes (receiverwidget.cpp:82); the one-channel, one-super-frame shape
+    // banks (or calls of several super-frames): a per-channel threshold, decided on the device per (channel, super-frame)
+    std::vector<float> squelch_;      // per channel, -120 = never closes
+    bool bank_gate_ = false, squelch_dirty_ = false;
+    float *d_squelch = nullptr;
+    unsigned char *d_gate = nullptr;  // [C][max_sf]
     float4 *h_gate_ = nullptr;        // pinned: the S-meter value the gate reads back
     uint64_t squelched_calls = 0;
     bool failed_ = false;             // a process call failed after it had started queueing work: the handle is refused from then on

@@ -98,6 +98,8 @@ Receiver::~Receiver()
     agc_.release(); resamp_.release(); cond_.release(); anf_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
     if (h_gate_) (void)hipHostFree(h_gate_);
+    if (d_squelch) (void)hipFree(d_squelch);
+    if (d_gate) (void)hipFree(d_gate);
     if (d_raw_stage_) (void)hipFree(d_raw_stage_);
     if (d_smeter) (void)hipFree(d_smeter);
     if (d_sm_bins) (void)hipFree(d_sm_bins);
@@ -155,9 +157,26 @@ int Receiver::enable_smeter(bool on)
 int Receiver::set_squelch(uint32_t ch, double squelch_db)
 {
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u of %u", ch, C);
+    if (C != 1 || max_sf != 1) {
+        // a bank, or calls of several super-frames: per-channel thresholds, the decision per (channel, super-frame) on the device
+        if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the per-channel gate of a bank is built for the narrow branch (a WFM receiver gates as one channel, one super-frame per call)");
+        if (squelch_db > -120.0) {
+            if (int rc = enable_smeter(true)) return rc;
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        PG_HIP(hipSetDevice(device));
+        if (squelch_.empty()) squelch_.assign(C, -120.f);
+        if (!d_squelch) {
+            PG_HIP(hipMalloc((void **)&d_squelch, sizeof(float) * C));
+            PG_HIP(hipMalloc((void **)&d_gate, (size_t)C * max_sf));
+        }
+        squelch_[ch] = (float)squelch_db;
+        bank_gate_ = false;
+        for (float v : squelch_) bank_gate_ = bank_gate_ || v > -120.f;
+        squelch_dirty_ = true;
+        return 0;
+    }
     if (squelch_db > -120.0) {
-        if (C != 1 || max_sf != 1)
-            return fail(PEBBLEGPU_E_UNSUPPORTED, "the squelch gate is defined for a one-channel receiver called one super-frame at a time");
         if (int rc = enable_smeter(true)) return rc;
     }
     std::lock_guard<std::mutex> g(mu_);
@@ -239,6 +258,11 @@ int Receiver::apply_controls()
         PG_HIP(hipStreamSynchronize(stream_));
         sm_dirty_ = false;
     }
+    if (squelch_dirty_) {
+        PG_HIP(hipMemcpyAsync(d_squelch, squelch_.data(), sizeof(float) * C, hipMemcpyHostToDevice, stream_));
+        PG_HIP(hipStreamSynchronize(stream_));
+        squelch_dirty_ = false;
+    }
     if (wfm) return 0;
     for (uint32_t ch = 0; ch < C; ch++) {
         ChanCtl &c = ctl_[ch];
@@ -285,7 +309,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // side by side: the chain goes to its own stream while the display transform keeps the arithmetic units busy (only when
     // the chain's first kernel needs no LDS -- the transform's workgroups leave none -- and nothing downstream reads the
     // spectrum or a conditioned copy of the input)
-    const bool side = with_spectrum && with_chain && !profile_detail && squelch_db_ <= -120.0 && dec_.front_is_lds_free() && !cond_.any && !cond_.dirty;
+    const bool side = with_spectrum && with_chain && !profile_detail && squelch_db_ <= -120.0 && !bank_gate_ && dec_.front_is_lds_free() && !cond_.any && !cond_.dirty;
     if (chain_end_) {  // the previous call's chain may still be running on its own stream
         PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
         chain_end_ = nullptr;
@@ -364,6 +388,27 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         last_audio_n = 0;
         gate_closed = true;
         if (profile_detail) { if (wfm) PG_HIP(hipEventRecord(ev[4], cs)); }
+    } else if (!wfm && bank_gate_) {
+        // Per-channel squelch of a bank: the decision is made on the device from the S-meter of each super-frame's last raw frame
+        // (no read-back, no stream synchronisation); everything behind the band-pass then runs one super-frame at a time and
+        // leaves a closed channel alone -- no output, no state change: the reference's early return (receiver.cpp:962-965) per
+        // channel.  A closed (channel, super-frame) reads as silence in the bank's audio rows.
+        if (!with_spectrum) return fail(PEBBLEGPU_E_INVALID, "the squelch gate of a bank reads the spectra of the same call: create the bank with spectrum_bins");
+        const int k = (int)(n / superframe);
+        const long long spf = nd / k;
+        if (int rc = run_gate_eval(cs, d_smeter, smeter_pitch, (int)(superframe / nf), k, d_squelch, d_gate, (int)max_sf, C)) return rc;
+        for (int j = 0; j < k; j++) {
+            const Gate gate{d_gate, (int)max_sf, j};
+            float2 *seg = audio.data() + (long long)j * spf;
+            if (int rc = anf_.run(cs, seg, audio.pitch, spf, gate)) return rc;
+            if (int rc = agc_.run(cs, seg, audio.pitch, spf, gate)) return rc;
+            if (int rc = am_.run(cs, seg, audio.pitch, seg, audio.pitch, spf, gate)) return rc;
+            if (sam_.C) { if (int rc = sam_.run(cs, seg, audio.pitch, seg, audio.pitch, spf, gate)) return rc; }
+            if (nfm_.C) { if (int rc = nfm_.run(cs, seg, audio.pitch, seg, audio.pitch, spf, gate)) return rc; }
+        }
+        if (int rc = run_gate_zero(cs, audio.data(), audio.pitch, spf, d_gate, (int)max_sf, C, k)) return rc;
+        for (uint32_t ch = 0; ch < C; ch++)
+            if (ctl_[ch].mode == PEBBLEGPU_DM_NONE) PG_HIP(hipMemsetAsync(audio.data((int)ch), 0, sizeof(float2) * (size_t)nd, cs));
     } else if (!wfm) {
         if (int rc = anf_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
         if (int rc = agc_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983

@@ -486,3 +486,38 @@ def test_noise_floor_formula(oracle_mod, amp, n):
             acc.append(np.mean(10 ** (db / 10)))
     got = 10 * np.log10(np.mean(acc)) - 20 * np.log10(0.2)
     assert abs(got - (want + 10 * np.log10((1 + np.pi / 4) / 2))) < 0.1
+
+
+def test_agc_remembers_the_silence_it_started_in(oracle_mod):
+    """Why the device tests that run an AGC use a 5e-5 bar for the first half second and 1e-5 after it.  The AGC's detector is
+    log10(max(|re|, |im|) + 1e-8) (agc.cpp:119-121): while the band-pass is still filling, its output is ~1e-16..1e-9 and the
+    detector reads about -8; an ABSOLUTE error of 3e-8 there -- the fp32 floor of an overlap-save block whose later samples are
+    at full level -- reads -7.4 instead.  That start-up value seeds the decay average (time constants 30 / 100 ms), and its
+    trace is what sets the gain once the envelope falls: the oracle's own output, 100-250 ms later, moves by > 3e-6 when
+    nothing but the first 64 near-silent samples of its input are touched at the 3e-8 level.  Not chaos (cf. SAM): the trace
+    decays, by a factor e every 100 ms."""
+    O = oracle_mod
+    fs, fc = 2048000, 100e3
+    N = 16 * 32 * 2048
+    t = np.arange(N) / fs
+    x = 0.1 * (1 + 0.8 * np.sin(2 * np.pi * 3.0 * t)) * np.exp(2j * np.pi * (fc + 1000) * t) + lcg_noise(N, 9, 1e-4)
+    mix = O.Mixer(fs); mix.set_frequency(fc)
+    dec = O.Decimator(fs, 30000)
+    z = np.concatenate([dec.process(mix.process(x[i:i + 8192])) for i in range(0, N, 8192)]) * 10 ** (2 * 5 / 20.0)
+    ff = O.FastFIR(); ff.setup(300, 3000, 0, 64000)
+    y = np.concatenate([ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048)])
+    assert np.abs(y[:8]).max() < 1e-9 and np.abs(y[600:700]).min() > 1e-2   # the filter fills within a few hundred samples
+
+    def agc(v):
+        a = O.Agc(64000); a.set_mode(1, 20)
+        return np.concatenate([a.process(v[k:k + 2048]) for k in range(0, len(v), 2048)])
+
+    base = agc(y)
+    y2 = y.copy()
+    y2[:64] += 3e-8 * np.exp(2j * np.pi * np.arange(64) / 7.0)
+    pert = agc(y2)
+    rr = lambda k: float(np.sqrt(np.mean(np.abs(pert[k * 2048:(k + 1) * 2048] - base[k * 2048:(k + 1) * 2048]) ** 2)) /
+                         np.sqrt(np.mean(np.abs(base[k * 2048:(k + 1) * 2048]) ** 2)))
+    assert rr(2) < 1e-7          # while the attack average rules the gain, nothing shows
+    assert rr(5) > 3e-6          # 160-190 ms in: the decay average, seeded at start-up, now does
+    assert rr(15) < rr(5) / 10   # and its trace fades (half a second in: below 1e-6)

@@ -14,6 +14,12 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 TOL_DB = 0.1
+# Paths through a running AGC, during the first half second of a stream: the AGC's log detector turns the fp32 floor of the
+# band-pass output's first, near-silent samples (3e-8 absolute, under full-level samples of the same overlap-save block) into a
+# different start-up value of its decay average, whose trace (100 ms time constant) sets the gain later on.  The oracle does
+# the same to itself: tests/test_oracle_pins.py::test_agc_remembers_the_silence_it_started_in.  The AGC kernel itself matches
+# the oracle's AGC to 3e-8 on identical input (tools/diag/agc_iso.py).
+TOL_AGC_STARTUP = 5e-5
 
 
 def rel_rms(a, b):
@@ -778,14 +784,14 @@ def test_squelch_gate_is_the_reference_early_return(gpu_lib, oracle_mod, wfm):
         assert len(g) == len(r), "super-frame %d" % k
         assert (len(g) > 0) == bool(on)
         if on:
-            assert rel_rms(g, r) <= (2e-5 if not wfm else TOL), "super-frame %d" % k
+            assert rel_rms(g, r) <= (TOL_AGC_STARTUP if not wfm else TOL), "super-frame %d" % k  # the narrow case runs AGC_FAST
     # -120 (DB::minDb) never gates: the silent super-frame is demodulated again
     rx.set_squelch(0, -120.0); ref.set_squelch(-120.0)
     g = rx.process(x[2 * sf:3 * sf])[0][0]
     assert len(g) > 0
-    bank = P.ReceiverBank(fs, 2, True, False, bins, max_superframes=1)
+    wbank = P.ReceiverBank(fs, 2, True, True, bins, max_superframes=1)
     with pytest.raises(P.PebbleGpuError):
-        bank.set_squelch(0, -60.0)  # defined for the reference's shape: one channel, one super-frame per call
+        wbank.set_squelch(0, -60.0)  # a WFM receiver gates in the reference's own shape only (narrow banks: test_squelch_in_a_bank)
 
 
 def test_squelch_on_the_single_frame_host_path(gpu_lib, oracle_mod):
@@ -1316,8 +1322,7 @@ def test_tune_only_mode_freezes_what_lies_behind_it(gpu_lib, oracle_mod, C):
                 assert (g.shape[1] == 0) if C == 1 else (g.shape[1] == 2048 and not g[c].any())
             else:
                 assert g[c].shape == r.shape
-                # the fast AGC multiplies the fp32 input error by its gain slope: 2e-5 (see test_squelch_gate_*), not 1e-5
-                assert rel_rms(g[c], r) <= 2e-5, "super-frame %d channel %d" % (k, c)
+                assert rel_rms(g[c], r) <= TOL_AGC_STARTUP, "super-frame %d channel %d" % (k, c)
 
 
 @pytest.mark.parametrize("wfm", [False, True])
@@ -1349,3 +1354,66 @@ def test_zoomed_spectrum_of_the_decimated_frames(gpu_lib, oracle_mod, wfm):
         assert Z[c].shape == ref.shape
         for f in range(1, len(ref)):
             assert db_err(Z[c][f], ref[f]) <= TOL_DB, "channel %d frame %d" % (c, f)
+
+
+def test_squelch_in_a_bank(gpu_lib, oracle_mod):
+    """The gate per channel of a bank (receiver.cpp:959-965 once per Receiver): three channels off one stream -- AM with a fast AGC,
+    USB, and NFM -- each with its own carrier keyed on and off per super-frame in its own pattern, thresholds -60 / -60 / -120
+    (never gates), several super-frames per call.  Against one oracle Receiver per channel: an open super-frame's audio matches
+    the oracle's (whose AGC, demodulator and filter states slept through the closed ones), a closed one is silence in the
+    bank's row where the oracle delivers nothing."""
+    import pebblesdr_amd as P
+    fs, n, bins = 2048000, 2048, 4096
+    fcs = [100e3, -250e3, 400e3]
+    modes = [(P.DM_AM, oracle_mod.AM, -5000, 5000), (P.DM_USB, oracle_mod.USB, 300, 3000), (P.DM_FMN, oracle_mod.FMN, -7500, 7500)]
+    thr = [-60.0, -60.0, -120.0]
+    C = 3
+    rx = P.ReceiverBank(fs, C, True, False, bins, max_superframes=3)
+    refs = []
+    for c in range(C):
+        gm, om, lo, hi = modes[c]
+        rx.set_mode(c, gm); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, lo, hi)
+        r = oracle_mod.Receiver(fs, n, bins)
+        r.set_mode(om); r.set_mixer(fcs[c]); r.set_filter(lo, hi)
+        if c == 0:
+            rx.set_agc(c, 1, 20); r.set_agc(1, 20)
+        rx.set_squelch(c, thr[c]); r.set_squelch(thr[c])
+        refs.append(r)
+    sf = rx.superframe
+    patterns = [[1, 0, 1, 1, 0, 0, 1, 1], [0, 1, 1, 0, 1, 0, 0, 1], [1, 0, 0, 1, 1, 1, 0, 1]]
+    K = len(patterns[0])
+    N = K * sf
+    t = np.arange(N) / fs
+    x = lcg_noise(N, 9, 1e-5)
+    for c in range(C):
+        env = np.repeat(np.asarray(patterns[c], dtype=np.float64), sf)
+        if c == 0:
+            x = x + env * 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 700 * t)) * np.exp(2j * np.pi * fcs[c] * t)
+        elif c == 1:
+            x = x + env * 0.1 * np.exp(2j * np.pi * (fcs[c] + 1300.0) * t)
+        else:
+            x = x + env * 0.1 * np.exp(1j * (2 * np.pi * fcs[c] * t + 2.0 * np.sin(2 * np.pi * 800 * t)))
+    # oracle, frame by frame: per super-frame either its audio or nothing
+    want = [[None] * K for _ in range(C)]
+    for c in range(C):
+        for k in range(K):
+            a = [refs[c].process(x[k * sf + f * n:k * sf + (f + 1) * n], want_spectrum=True)[0] for f in range(sf // n)]
+            want[c][k] = np.concatenate(a)
+    got = np.concatenate([rx.process(x[lo * sf:hi * sf])[0] for lo, hi in ((0, 3), (3, 4), (4, 6), (6, 8))], axis=1)
+    assert got.shape == (C, K * 2048)
+    opened = 0
+    for c in range(C):
+        for k in range(K):
+            g = got[c, k * 2048:(k + 1) * 2048]
+            if len(want[c][k]) == 0:
+                assert thr[c] > -120 and not patterns[c][k]
+                assert not g.any(), "channel %d super-frame %d should be gated" % (c, k)
+            else:
+                opened += 1
+                assert len(want[c][k]) == 2048
+                if c == 2 and (k == 0 or not patterns[c][k] or not patterns[c][k - 1]):
+                    continue  # NFM on noise alone (never gated here: its PLL wanders) or re-acquiring behind it: compared once locked
+                    # (see test_bank_with_every_narrow_demod_mode)
+                bar = TOL_AGC_STARTUP if c == 0 else (2e-5 if c == 2 else TOL)
+                assert rel_rms(g, want[c][k]) <= bar, "channel %d super-frame %d" % (c, k)
+    assert opened >= 12
