@@ -1337,7 +1337,8 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         // (one 64 MiB buffer reused by every batch), instead of a call-sized Y that went out to HBM and back
         // (28 B moved per 12 B of algorithmic traffic).
         const long long per_stream = (long long)F * kBigN;                       // Y points per stream
-        long long bs = (64LL << 20) / (long long)sizeof(float2) / per_stream;    // streams per batch
+        static const long long batch_mb = [] { const char *e = getenv("PEBBLEGPU_BIG_BATCH_MB"); return e ? atoll(e) : 0LL; }();  // 0: the whole call in one pair of launches (measured: 16 / 32 / 64 / 128 MiB batches 0.61 / 0.48 / 0.39 / 0.34 ms against 0.34 whole: the kernels are not bound by that traffic)
+        long long bs = batch_mb > 0 ? (batch_mb << 20) / (long long)sizeof(float2) / per_stream : (long long)S;    // streams per batch
         bs = bs < 1 ? 1 : (bs > (long long)S ? (long long)S : bs);
         const size_t need = (size_t)bs * (size_t)per_stream;
         if (need > y_cap) {

@@ -533,10 +533,26 @@ static __global__ __launch_bounds__(256) void k_big_cols(const float2 *__restric
     for (int n1 = 0; n1 < kBigR; n1++) u[n1] = cscale(x[(long long)kBigM * n1], window[kBigM * n1 + n2]);
     dft32(u);
     float2 *y = Y + ((long long)s * n_frames + f) * kBigN + n2;
+    // W_N^{n2 k1}, k1 < 32, from ONE exact phasor w = W_N^{n2}: k1 = 4 hi + lo, tw = w^(4 hi) * w^lo from two small tables built with
+    // ten products (at most four deep), then one product per output -- instead of a fp64 range reduction and a sincos per output
+    float2 lo[4], hi[8];
+    lo[0] = make_float2(1.f, 0.f);
+    lo[1] = cis_cycles(-(double)n2 / (double)kBigN);
+    lo[2] = cmul(lo[1], lo[1]);
+    lo[3] = cmul(lo[2], lo[1]);
+    hi[0] = lo[0];
+    hi[1] = cmul(lo[2], lo[2]);
+    hi[2] = cmul(hi[1], hi[1]);
+    hi[3] = cmul(hi[2], hi[1]);
+    hi[4] = cmul(hi[2], hi[2]);
+    hi[5] = cmul(hi[4], hi[1]);
+    hi[6] = cmul(hi[4], hi[2]);
+    hi[7] = cmul(hi[4], hi[3]);
 #pragma unroll
     for (int k1 = 0; k1 < kBigR; k1++) {
-        const float2 tw = cis_cycles(-(double)(n2 * k1) / (double)kBigN);  // W_N^{n2 k1}
-        y[(long long)kBigM * k1] = cmul(u[perm32(k1)], tw);
+        const float2 v = u[perm32(k1)];
+        const float2 tw = (k1 & 3) == 0 ? hi[k1 >> 2] : (k1 >> 2) == 0 ? lo[k1 & 3] : cmul(hi[k1 >> 2], lo[k1 & 3]);
+        y[(long long)kBigM * k1] = k1 == 0 ? v : cmul(tw, v);
     }
 }
 
@@ -616,6 +632,9 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
     }
 }
 
+// (Pass B was also built on the two-wave transform of fft_t128.h -- 512-item workgroups, four rows x two waves, four waves per
+// SIMD -- and measured slower, 0.39 ms against 0.32 for the bench shard: its rows wait on workgroup-wide barriers and on their
+// own loads, where here every wave runs alone.)
 // ------------------------------------------------------------------------------------------------
 // SignalStrength::fdEstimate (application/signalstrength.cpp:287-380) on every frame of the unprocessed spectrum: peak and
 // average power inside the band-pass window around the mixer frequency, average power of one window width either side
