@@ -226,10 +226,11 @@ void OscBank::advance(uint64_t n)
     }
 }
 
-int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait)
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale)
 {
     double scale = gain;
-    if (fmt == 0 || fmt == 1) scale *= 1 / 128.0;        // deviceinterfacebase.cpp:651,689
+    if (final_scale != 0.f) scale = (double)final_scale;  // the caller has already folded the format's constant in
+    else if (fmt == 0 || fmt == 1) scale *= 1 / 128.0;   // deviceinterfacebase.cpp:651,689
     else if (fmt == 2) scale *= 1 / 32768.0;             // :729
     else if (fmt == 4) scale *= 1 / 32767.0;             // wavfile.cpp:299-300
     long long blocks = (n + 255) / 256;
@@ -422,8 +423,9 @@ void DecimCore::release()
     }
 }
 int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
-                   hipEvent_t after_first)
+                   hipEvent_t after_first, const RawSrc *raw)
 {
+    if (raw && !raw_ready(osc)) return fail(PEBBLEGPU_E_INVALID, "raw-format input reached a decimator path that has no converting loads");
     if (n <= 0 || n % (long long)chain.total != 0)
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
@@ -480,12 +482,13 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             // (a handful of lanes) for the first outputs, whose windows reach back into the mixed history, and the new history
             const int R = 8;
             const long long j_first = (10 + first.stride - 1) / first.stride;
-            launch(k_mix_hb11_lean, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc, osc.a_inf, bank_taps,
-                   first.gain, osc.inline_dyn, R, j_first);
+            const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
+            launch(raw ? k_mix_hb11_lean<true> : k_mix_hb11_lean<false>, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc,
+                   osc.a_inf, bank_taps, first.gain, osc.inline_dyn, R, j_first, rs);
             front_name = "k_mix_hb11_lean";
-            launch(k_mix_hb11_bank<false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch, (int)shared_input, buf0.data(), buf0.pitch,
-                   len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
-                   (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first);
+            launch(raw ? k_mix_hb11_bank<false, false, true> : k_mix_hb11_bank<false, false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch,
+                   (int)shared_input, buf0.data(), buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1],
+                   (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first, rs);
         } else if (bank_front && (C >= 16 ? shared_input : want_lds_free)) {
  // a bank off one shared stream: lanes = channels, windows in registers (k_mix_hb11_bank)
             int cl_log2 = 0;
@@ -497,7 +500,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
                                             : (uni ? k_mix_hb11_bank<false, true> : k_mix_hb11_bank<false, false>);
             launch_lds(kern, grid, dim3(256), cl_log2 ? 4 * (size_t)front_tile_slots(cl_log2, R) * sizeof(float2) : 0, s, d_in, in_pitch, (int)shared_input, buf0.data(),
                        buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1], (int)kMaxTaps,
-                       (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, cl_log2, (int)C, R, -1LL);
+                       (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, cl_log2, (int)C, R, -1LL, RawSrc{nullptr, 0, 0, 0.f, 0});
             front_name = "k_mix_hb11_bank";
         } else {
         // merged CIC3 over a shared stream: one workgroup mixes a group of channels from one fetch of the sample pairs
@@ -1325,8 +1328,9 @@ void SpectrumCore::release()
     d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr; d_btab128 = d_tw128 = nullptr;
     y_cap = 0;
 }
-int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out)
+int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out, const RawSrc *raw)
 {
+    if (raw && !raw_ready()) return fail(PEBBLEGPU_E_INVALID, "raw-format input reached a spectrum kernel that has no converting loads");
     SpectrumParams sp;
     sp.in_pitch = in_pitch;
     sp.n_frames = F;
@@ -1392,12 +1396,26 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         sp.frames_per_group = (int)G8;
         sp.scale = scale;
         sp.out_pitch = F * (long long)bins;
-        if (stagger > 0)  // two chains per 1024-item workgroup, the second `stagger` barrier intervals behind the first
-            launch(k_spectrum_t128<2>, dim3(cdiv(cdiv(F, G8), 2), S), dim3(1024), s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
-                   (const float *)d_prev[parity], d_prev[parity ^ 1], sp, stagger);
+        const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
+        const float *pin = d_prev[parity];
+        float *pout = d_prev[parity ^ 1];
+        if (raw) {  // raw-format frames take the two-chain kernel (one instantiation per sample format)
+            const dim3 grid(cdiv(cdiv(F, G8), 2), S), block(1024);
+            const int st = stagger > 0 ? stagger : 7;
+            auto go = [&](auto kern) { launch(kern, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, st, rs); };
+            switch (raw->fmt) {
+            case 0: go(k_spectrum_t128<2, 0>); break;
+            case 1: go(k_spectrum_t128<2, 1>); break;
+            case 2: go(k_spectrum_t128<2, 2>); break;
+            case 3: go(k_spectrum_t128<2, 3>); break;
+            default: go(k_spectrum_t128<2, 4>); break;
+            }
+        } else if (stagger > 0)  // two chains per 1024-item workgroup, the second `stagger` barrier intervals behind the first
+            launch(k_spectrum_t128<2, -1>, dim3(cdiv(cdiv(F, G8), 2), S), dim3(1024), s, d_in, d_out, (const float *)d_window,
+                   (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, stagger, rs);
         else
-            launch_lds(k_spectrum_t128<1>, dim3(cdiv(F, G8), S), dim3(512), (size_t)pad_lds, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128,
-                       (const float *)d_prev[parity], d_prev[parity ^ 1], sp, 0);
+            launch_lds(k_spectrum_t128<1, -1>, dim3(cdiv(F, G8), S), dim3(512), (size_t)pad_lds, s, d_in, d_out, (const float *)d_window,
+                       (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, 0, rs);
         parity ^= 1;
         PG_HIP(hipGetLastError());
         return 0;

@@ -463,14 +463,15 @@ static __global__ __launch_bounds__(256) void k_mix_cic_hb(const float2 *__restr
 //   y[o] = sum_p m[o S + p - 10] h[p]  (decimator.cpp:637-648), m = osc * x; m[i < 0] from `hist` ([channel][10] mixed)
 //   the virtual output o = n_out mixes the call's last ten samples into hist_out for the next call.
 // grid (ceil((n_out + 1) / (4 R 64/CL)), ceil(C / CL)), block 256 (four independent waves, R outputs per lane each).
-template <bool TRANSIENT, bool UNIFORM /* as in k_mix_cic_hb */>
+template <bool TRANSIENT, bool UNIFORM /* as in k_mix_cic_hb */, bool RAW = false /* raw device-format input (RawSrc), one stream */>
 static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__restrict__ in, long long in_pitch, int shared_input,
                                                                float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                                const ChanOsc *__restrict__ osc, const float2 *__restrict__ hist,
                                                                float2 *__restrict__ hist_out, int hist_pitch, const float *__restrict__ amp_tab,
                                                                float a_inf, FrontTaps hb /* stage 0: hb11 */, float out_gain, OscDynInline dyn,
                                                                int cl_log2, int n_chan, int R,
-                                                               long long edges_below /* >= 0: only outputs j < edges_below and the history */)
+                                                               long long edges_below /* >= 0: only outputs j < edges_below and the history */,
+                                                               RawSrc raw = RawSrc{nullptr, 0, 0, 0.f, 0})
 {
     constexpr int T = kFrontT1, H = T - 1;
     HIP_DYNAMIC_SHARED(float2, tiles)
@@ -506,7 +507,14 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
     // the six 16-byte loads of a window; pairs before the call's start are clamped here and patched from `hist` below
     auto load_window = [&](long long jj, float4 (&w)[6]) {
         const long long i0 = (long long)S * jj - H;
-        if (i0 >= 0) {  // one address, six immediate offsets
+        if (RAW) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const long long i = i0 + 2 * k > 0 ? i0 + 2 * k : 0;
+                const float2 a = raw_load(raw, i), b = raw_load(raw, i + 1);
+                w[k] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        } else if (i0 >= 0) {  // one address, six immediate offsets
             const float4 *p = reinterpret_cast<const float4 *>(in_c + i0);
 #pragma unroll
             for (int k = 0; k < 6; k++) w[k] = p[k];
@@ -528,7 +536,7 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
 #pragma unroll 1
             for (int q = 0; q < H; q++) {
                 const long long i = n - H + q;
-                float2 v = in_c[i];
+                float2 v = RAW ? raw_load(raw, i) : in_c[i];
                 if (mix_on != 0) v = cmul(cscale(cis_cycles(phase0 + (double)(i + 1) * inc), osc_amp(amp_tab, a_inf, n0, i)), v);
                 hp[q] = v;
             }
@@ -593,9 +601,10 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
 // with pa(j) = a_inf e^{j 2 pi (phase0 + (S j - 9) inc)}: seven complex MACs and one product per output instead of
 // thirteen products and seven MACs.
 // grid ceil(n_out / (4 R 64)), block 256 (four independent waves, R outputs per lane each).
+template <bool RAW /* raw device-format input (RawSrc) converted in the window loads */>
 static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *__restrict__ in, float2 *__restrict__ out, long long n_out,
                                                                   const ChanOsc *__restrict__ osc, float a_inf, FrontTaps hb, float out_gain,
-                                                                  OscDynInline dyn, int R, long long j_first)
+                                                                  OscDynInline dyn, int R, long long j_first, RawSrc raw)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = hb.stride;
@@ -619,15 +628,23 @@ static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *_
         // (before the range test: a lane that sits out its first output must still carry the phase to its later ones)
         if (mix) ph = r == 0 ? cscale(cis_cycles(phase0 + (double)(i0 + 1) * inc), a_inf * out_gain) : cmul(rot, ph);
         if (j < j_first || j >= n_out) continue;
-        const float4 *p = reinterpret_cast<const float4 *>(in + i0);
-        const float4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], x5 = p[5];
-        float2 acc = cscale(make_float2(x0.x, x0.y), h0);
-        acc = cadd(acc, cmul(c2, make_float2(x1.x, x1.y)));
-        acc = cadd(acc, cmul(c4, make_float2(x2.x, x2.y)));
-        acc = cadd(acc, cmul(c5, make_float2(x2.z, x2.w)));
-        acc = cadd(acc, cmul(c6, make_float2(x3.x, x3.y)));
-        acc = cadd(acc, cmul(c8, make_float2(x4.x, x4.y)));
-        acc = cadd(acc, cmul(c10, make_float2(x5.x, x5.y)));
+        float2 s0, s2, s4, s5, s6, s8, s10;
+        if (RAW) {
+            s0 = raw_load(raw, i0); s2 = raw_load(raw, i0 + 2); s4 = raw_load(raw, i0 + 4); s5 = raw_load(raw, i0 + 5);
+            s6 = raw_load(raw, i0 + 6); s8 = raw_load(raw, i0 + 8); s10 = raw_load(raw, i0 + 10);
+        } else {
+            const float4 *p = reinterpret_cast<const float4 *>(in + i0);
+            const float4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], x5 = p[5];
+            s0 = make_float2(x0.x, x0.y); s2 = make_float2(x1.x, x1.y); s4 = make_float2(x2.x, x2.y); s5 = make_float2(x2.z, x2.w);
+            s6 = make_float2(x3.x, x3.y); s8 = make_float2(x4.x, x4.y); s10 = make_float2(x5.x, x5.y);
+        }
+        float2 acc = cscale(s0, h0);
+        acc = cadd(acc, cmul(c2, s2));
+        acc = cadd(acc, cmul(c4, s4));
+        acc = cadd(acc, cmul(c5, s5));
+        acc = cadd(acc, cmul(c6, s6));
+        acc = cadd(acc, cmul(c8, s8));
+        acc = cadd(acc, cmul(c10, s10));
         out[j] = mix ? cmul(ph, acc) : cscale(acc, out_gain);
     }
 }

@@ -195,14 +195,18 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 // vector ALU busy 63 %, LDS 41 %, the frame time their SUM).  Here the barriers are common to both halves and the second half
 // runs `shift` barrier intervals behind the first, so that in every interval one half's butterflies meet the other's exchange:
 // the offset is fixed by construction, not left to the dispatcher.
-template <int HALVES>
+// FMT >= 0: the frames are read in the device's own sample format (RawSrc, pebblegpu_iq_format FMT) and converted in the load --
+// normalizeIQ without a float2 copy of the stream (2 instead of 8 bytes per sample from HBM for HackRF / RTL int8 pairs).  A
+// work-item then takes four CONSECUTIVE samples (one 8- or 16-byte load) instead of four samples 512 apart.
+template <int HALVES, int FMT>
 static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
                                                                  const float *__restrict__ window, const float2 *__restrict__ btab128,
                                                                  const float2 *__restrict__ tw128, const float *__restrict__ prev_in,
-                                                                 float *__restrict__ prev_out, SpectrumParams sp, int shift)
+                                                                 float *__restrict__ prev_out, SpectrumParams sp, int shift, RawSrc raw)
 {
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP, XOFF = NF / 2;
     constexpr int REGION = FftLds<NF>::kSlots;
+    constexpr bool RAW = FMT >= 0;
     __shared__ float2 lds_all[HALVES][4][REGION];
     __shared__ float2 tw_lds[kTw128Count];
     const int tid = threadIdx.x & 511, lane = tid & 63;
@@ -219,22 +223,29 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     for (int i = threadIdx.x; i < kTw128Count; i += 512 * HALVES) tw_lds[i] = tw128[i];
     float win[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) win[i] = window[tid + 512 * i];
+    for (int i = 0; i < 4; i++) win[i] = RAW ? window[4 * tid + i] : window[tid + 512 * i];
     const int t0 = (wave & 1) * 64 + lane;                                   // work-item of its transform, 0..127
     const float2 tw_lane = cis_cycles(-(double)(t0 * q) / (double)BINS);     // W_bins^{t q}
     const float2 *bq = btab128 + q * E;                                      // W_bins^{128 m q}, m < 16 (wave-uniform)
     const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float pa[E];
     float2 xn[4];
-    auto park = [&](int tt) {  // sample n = tt + 512 i goes to region i, slot XOFF + tt
+    auto park = [&](int tt) {  // sample n = tt + 512 i goes to region i, slot XOFF + tt (RAW: n = 4 tt + i: region tt / 128, four adjacent slots)
 #pragma unroll
-        for (int i = 0; i < 4; i++) lds[i][XOFF + tt] = cscale(xn[i], win[i]);
+        for (int i = 0; i < 4; i++) {
+            if (RAW) lds[tt >> 7][XOFF + ((4 * tt + i) & 511)] = cscale(xn[i], win[i]);
+            else lds[i][XOFF + tt] = cscale(xn[i], win[i]);
+        }
     };
     {
         const long long ff = f0 > 0 ? f0 - 1 : 0;
         if (ff < sp.n_frames) {
+            if (RAW) {
+                raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + ff * NF + 4 * tid, xn);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) xn[i] = x[ff * NF + tid + 512 * i];
+                for (int i = 0; i < 4; i++) xn[i] = x[ff * NF + tid + 512 * i];
+            }
             park(tid);
         }
     }
@@ -250,9 +261,13 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         opaque(td);
         const bool fetch = it + 1 < G && f + 1 < sp.n_frames && f >= 0;
         if (fetch) {
-            const float2 *xp = x + (f + 1) * NF + td;
+            if (RAW) {
+                raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + (f + 1) * NF + 4 * td, xn);
+            } else {
+                const float2 *xp = x + (f + 1) * NF + td;
 #pragma unroll
-            for (int i = 0; i < 4; i++) xn[i] = xp[512 * i];
+                for (int i = 0; i < 4; i++) xn[i] = xp[512 * i];
+            }
         }
         float2 v[E];
         if (xform) {

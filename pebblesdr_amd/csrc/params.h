@@ -91,6 +91,65 @@ struct TailJobs {
     TailJob job[kMaxTailJobs];
 };
 
+// A stream still in the device's own sample format (DeviceInterfaceBase::normalizeIQ, pebblelib/deviceinterfacebase.cpp:648-838, done
+// in the first loads of the kernels that take it instead of a separate pass): base == nullptr: the float2 pointer is the input.
+//   fmt 0 CPX8 int8 pairs, 1 CPXU8 (v - 128), 2 CPX16, 3 CPXFLOAT, 4 WAV PCM16; order 0 IQ, 1 QI, 2 I only, 3 Q only; scale includes the gain
+struct RawSrc {
+    const void *base;
+    int fmt, order;
+    float scale;
+    int pad_;
+};
+__device__ __forceinline__ float2 raw_load(const RawSrc &r, long long i)
+{
+    float a, b;
+    if (r.fmt == 0) {
+        const char2 v = reinterpret_cast<const char2 *>(r.base)[i];
+        a = (float)v.x; b = (float)v.y;
+    } else if (r.fmt == 1) {
+        const uchar2 v = reinterpret_cast<const uchar2 *>(r.base)[i];
+        a = (float)v.x - 128.0f; b = (float)v.y - 128.0f;
+    } else if (r.fmt == 2 || r.fmt == 4) {
+        const short2 v = reinterpret_cast<const short2 *>(r.base)[i];
+        a = (float)v.x; b = (float)v.y;
+    } else {
+        const float2 v = reinterpret_cast<const float2 *>(r.base)[i];
+        a = v.x; b = v.y;
+    }
+    a *= r.scale;
+    b *= r.scale;
+    return r.order == 0 ? make_float2(a, b) : r.order == 1 ? make_float2(b, a) : r.order == 2 ? make_float2(a, a) : make_float2(b, b);
+}
+
+// four consecutive samples i .. i + 3 (i a multiple of 4) in one or two wide loads: 8 bytes for the int8 formats, 16 for int16, 32 for float
+template <int FMT>
+__device__ __forceinline__ void raw_load4(const RawSrc &r, long long i, float2 (&o)[4])
+{
+    float v[8];
+    if (FMT == 0 || FMT == 1) {
+        const uint2 w = reinterpret_cast<const uint2 *>(r.base)[i >> 2];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned word = k < 4 ? w.x : w.y;
+            const int sh = 8 * (k & 3);
+            v[k] = FMT == 0 ? (float)((int)(word << (24 - sh)) >> 24) : (float)((word >> sh) & 0xFFu) - 128.0f;
+        }
+    } else if (FMT == 2 || FMT == 4) {
+        const uint4 w = reinterpret_cast<const uint4 *>(r.base)[i >> 2];
+        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (float)((int)(ww[k >> 1] << (16 - 16 * (k & 1))) >> 16);
+    } else {
+        const float4 a = reinterpret_cast<const float4 *>(r.base)[i >> 1], b = reinterpret_cast<const float4 *>(r.base)[(i >> 1) + 1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float a = v[2 * k] * r.scale, b = v[2 * k + 1] * r.scale;
+        o[k] = r.order == 0 ? make_float2(a, b) : r.order == 1 ? make_float2(b, a) : r.order == 2 ? make_float2(a, a) : make_float2(b, b);
+    }
+}
+
 // Per-channel squelch gate of a bank (receiver.cpp:959-965 per channel): open[c * stride + j] != 0 <=> channel c's super-frame j of
 // this call passes.  The kernels behind the band-pass take one super-frame j at a time and leave a closed channel alone
 // (no output, no state change).  open == nullptr: no gate.

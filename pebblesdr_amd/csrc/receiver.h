@@ -37,7 +37,7 @@ int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
-int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait);
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale = 0.f);
 int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
                   int stride, uint32_t channels);
 int run_gate_zero(hipStream_t s, float2 *audio, long long pitch, long long spf, const unsigned char *d_gate, int stride, uint32_t channels, int k);
@@ -106,7 +106,9 @@ struct DecimCore {
     void release();
     // n must be a multiple of chain.total; any such n streams exactly (no minimum frame length)
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
-            hipEvent_t after_first = nullptr);
+            hipEvent_t after_first = nullptr, const RawSrc *raw = nullptr);
+    // the first kernels this call would run read raw device-format samples themselves (k_mix_hb11_lean + its edge launch)
+    bool raw_ready(const OscBank &osc) const { return bank_front && C == 1 && want_lds_free && !osc.any_transient() && !(fused_all); }
     void tail_jobs(std::vector<TailJob> &jobs) const;  // after run(): what must be refreshed before the next call
     const HistBuf &out() const { return casc.nst > 0 ? fin : buf0; }
     long long out_len() const { return len_out; }
@@ -281,7 +283,8 @@ struct SpectrumCore {
     int parity = 0;
     int init(uint32_t streams, uint32_t frame, uint32_t fft_size);
     void release();
-    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out);
+    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, const RawSrc *raw = nullptr);
+    bool raw_ready() const { return !big && !per_q && bins == 8192; }  // k_spectrum_t128 converts in its loads
 };
 
 // HIP events around each kernel group, kept for the last kRing calls so a caller can run calls back to back
@@ -306,7 +309,7 @@ public:
     int set_noise_filter(uint32_t ch, bool on);
     int process_raw(int fmt, int order, double gain, const void *d_raw, uint64_t n);  // normalizeIQ on the library's stream, then process()
     int set_squelch(uint32_t ch, double squelch_db);   // Receiver::squelchChanged, receiver.cpp:704-707
-    int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain);
+    int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain, const RawSrc *raw = nullptr);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();
     const char *kernel_name(int which) const;  // the kernels behind pebblegpu_receiver_last_ms's groups, as last run

@@ -295,12 +295,12 @@ int Receiver::apply_controls()
     return 0;
 }
 
-int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain)
+int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain, const RawSrc *raw)
 {
     std::lock_guard<std::mutex> g(mu_);
     PG_HIP(hipSetDevice(device));
     if (failed_) return fail(PEBBLEGPU_E_HIP, "an earlier call on this receiver failed half-way (its filter histories no longer match its oscillators): destroy it");
-    if (!d_iq || n == 0) return fail(PEBBLEGPU_E_INVALID, "null input or zero samples");
+    if ((!d_iq && !raw) || n == 0) return fail(PEBBLEGPU_E_INVALID, "null input or zero samples");
     if (with_chain && (n % superframe != 0 || n / superframe > max_sf))
         return fail(PEBBLEGPU_E_SIZE, "n_samples %llu is not 1..%u super-frames of %llu", (unsigned long long)n, max_sf,
                     (unsigned long long)superframe);
@@ -316,6 +316,20 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     }
     if (int rc = apply_controls()) return rc;
     if (int rc = cond_.apply(stream_)) return rc;
+    if (raw) {
+        // Raw device-format input: when the call's first kernels convert in their own loads (the 8192-bin display transform
+        // and the one-channel first stage beside it) there is no float2 copy of the stream at all; otherwise normalizeIQ runs
+        // as its own pass into a staging buffer and the call goes on from there.
+        dec_.want_lds_free = side;
+        const bool fused = side && S == 1 && spec_.raw_ready() && dec_.raw_ready(osc_);
+        if (!fused) {
+            if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
+            // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
+            if (int rc = run_normalize_iq(raw->fmt, raw->order, 1.0, raw->base, (long long)(S * n), d_raw_stage_, stream_, false, raw->scale)) return rc;
+            d_iq = d_raw_stage_;
+            raw = nullptr;
+        }
+    }
     long long in_pitch = (long long)n;
     // DCRemoval, IQBalance, NoiseBlanker 1/2 on the raw streams, ahead of the spectrum and the mixer (receiver.cpp:814-823)
     if (int rc = cond_.run(stream_, d_iq, in_pitch, (long long)n, &d_iq, &in_pitch)) return rc;
@@ -338,7 +352,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         }
     } guard{this, ev, cs, side, true};
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
-        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec)) return rc;
+        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec, raw)) return rc;
         last_spec_frames = n / nf;
         if (smeter_on) {
             const long long F = (long long)(n / nf);
@@ -356,7 +370,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
     dec_.want_lds_free = side;
     // an event record costs the stream a ~5 us bubble: per-kernel events only when asked for (set_profiling)
-    if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr)) return rc;
+    if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw)) return rc;
     if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
     const long long nd = dec_.out_len();
     if (zoom_bins) {  // SignalSpectrum::zoomed(m_sampleBuf, numStepSamples), receiver.cpp:884 / :942 (the update timer forced open)
@@ -454,18 +468,12 @@ int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, ui
     if (!d_raw || n == 0) return fail(PEBBLEGPU_E_INVALID, "null input or zero samples");
     if (fmt < 0 || fmt > 4 || order < 0 || order > 3) return fail(PEBBLEGPU_E_INVALID, "unknown sample format %d / IQ order %d", fmt, order);
     if (n > (uint64_t)max_sf * superframe) return fail(PEBBLEGPU_E_SIZE, "%llu samples exceed this object's capacity", (unsigned long long)n);
-    {
-        std::lock_guard<std::mutex> g(mu_);
-        PG_HIP(hipSetDevice(device));
-        if (chain_end_) {  // the previous call's chain may still be reading the staging buffer
-            PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
-            chain_end_ = nullptr;
-        }
-        if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
-        // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
-        if (int rc = run_normalize_iq(fmt, order, gain, d_raw, (long long)(S * n), d_raw_stage_, stream_, false)) return rc;
-    }
-    return process(d_raw_stage_, n, bins != 0, true);
+    double scale = gain;
+    if (fmt == 0 || fmt == 1) scale *= 1 / 128.0;        // deviceinterfacebase.cpp:651,689
+    else if (fmt == 2) scale *= 1 / 32768.0;             // :729
+    else if (fmt == 4) scale *= 1 / 32767.0;             // wavfile.cpp:299-300
+    const RawSrc raw{d_raw, fmt, order, (float)scale, 0};
+    return process(nullptr, n, bins != 0, true, &raw);
 }
 
 const char *Receiver::kernel_name(int which) const

@@ -1417,3 +1417,45 @@ def test_squelch_in_a_bank(gpu_lib, oracle_mod):
                 bar = TOL_AGC_STARTUP if c == 0 else (2e-5 if c == 2 else TOL)
                 assert rel_rms(g, want[c][k]) <= bar, "channel %d super-frame %d" % (c, k)
     assert opened >= 12
+
+
+@pytest.mark.parametrize("fmt,dtype,scale,order", [(0, np.int8, 128.0, 0), (1, np.uint8, 128.0, 1), (2, np.int16, 32768.0, 0), (4, np.int16, 32767.0, 3),
+                                                   (3, np.float32, 1.0, 1)])
+def test_process_raw_converting_in_the_first_loads(gpu_lib, fmt, dtype, scale, order):
+    """The bench's own shape fed in the device's sample format: at 20 Msps / 8192 bins / one channel the display transform and the
+    first decimator stage read the raw pairs themselves (k_spectrum_t128<.., RAW>, k_mix_hb11_lean<RAW>: no float2 copy of the
+    stream exists).  Every format and IQ order of normalizeIQ (deviceinterfacebase.cpp:648-838; WAV PCM16: wavfile.cpp:299-300)
+    must give, bit for bit, what process() gives on the same samples converted on the host with the same constants -- over two
+    calls, so the second one's first windows come from the history the first one left."""
+    import pebblesdr_amd as P
+    fs, bins = 20_000_000, 8192
+    a = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
+    b = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
+    for rx in (a, b):
+        rx.set_mixer(0, 1.0e6)
+    n = 4 * a.superframe
+    rng = np.random.default_rng(5)
+    t = np.arange(2 * n) / fs
+    sig = 0.4 * np.exp(1j * (2 * np.pi * 1.0e6 * t + 75.0 * np.sin(2 * np.pi * 1000 * t)))
+    if dtype == np.float32:
+        raw = np.stack([sig.real, sig.imag], axis=-1).astype(np.float32)
+        conv = raw * np.float32(0.5)
+    else:
+        off = 128.0 if dtype == np.uint8 else 0.0
+        raw = np.round(np.stack([sig.real, sig.imag], axis=-1) * (scale - 1) + off + rng.uniform(-1, 1, (2 * n, 2))).astype(dtype)
+        conv = (raw.astype(np.float32) - np.float32(off)) * np.float32(0.5 / scale)
+    i, q = conv[:, 0], conv[:, 1]
+    x = {0: i + 1j * q, 1: q + 1j * i, 2: i + 1j * i, 3: q + 1j * q}[order].astype(np.complex64)
+    for lo, hi in ((0, n), (n, 2 * n)):
+        buf = P.DeviceBuffer.from_array(raw[lo:hi], 0)
+        try:
+            a.process_raw_device(buf.ptr, n, fmt, order, 0.5)
+            ga, sa = a.audio(), a.spectrum()
+        finally:
+            buf.free()
+        gb, sb = b.process(x[lo:hi])
+        if lo:  # (the first call of a fresh receiver sits inside the oscillator's amplitude transient and takes the general route)
+            assert a.kernel_name(2) == "k_mix_hb11_lean" and a.kernel_name(1) == "k_spectrum_t128"
+        assert np.abs(ga).max() > 1e-3
+        assert np.array_equal(ga, gb)
+        assert np.array_equal(sa, sb)
