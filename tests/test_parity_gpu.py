@@ -191,6 +191,13 @@ def test_sam_pll_demod_step(gpu_lib, oracle_mod):
     for off, ln in ((0, n), (n, n), (2 * n, 2 * n), (4 * n, 1000)):
         R.append(ref.process(am[off:off + ln])); G.append(d.processBlock(am[off:off + ln]))
     r, g = np.concatenate(R), np.concatenate(G)
+    # the bar calibrates itself: the oracle against the oracle fed the same samples rounded to fp32 -- what the device's input
+    # format alone does to the reference algorithm (measured over rates and signals: device error 0.6-1.2x of it, tools/diag/pll_err.py)
+    ref32 = oracle_mod.DemodSAM(64000)
+    r32 = np.concatenate([ref32.process(am[off:off + ln].astype(np.complex64)) for off, ln in ((0, n), (n, n), (2 * n, 2 * n), (4 * n, 1000))])
+    own = rel_rms((r32.real + r32.imag) / 2, (r.real + r.imag) / 2)
+    assert own > 1e-7  # (it IS sensitive: a linear demodulator would read ~3e-8 here)
+    assert rel_rms((g.real + g.imag) / 2, (r.real + r.imag) / 2) <= max(TOL, 3 * own)
     assert rel_rms((g.real + g.imag) / 2, (r.real + r.imag) / 2) <= 1e-4
     gq, rq = (g.real - g.imag) / 2, (r.real - r.imag) / 2
     assert abs(np.std(gq[n:]) / np.std(rq[n:]) - 1) < 0.25
@@ -1082,7 +1089,8 @@ def test_demod_modes_at_the_other_demod_rates(gpu_lib, oracle_mod, fs, mode):
     r = np.concatenate([(dm.process(y) if dm else y) for y in (ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048))])
     assert r.shape == g.shape
     for k in range(1 if mode == "NFM" else 0, 3):
-        assert rel_rms(g[k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= (TOL if mode != "NFM" else 2e-5), "frame %d" % k
+        # NFM: measured 2e-6 .. 5e-6 in frame 1 and 2e-7 .. 4e-7 from frame 2 on at every rate (tools/diag/pll_err.py): the plain bar
+        assert rel_rms(g[k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL, "frame %d" % k
 
 
 @pytest.mark.parametrize("C", [16, 37, 100])
@@ -1414,7 +1422,7 @@ def test_squelch_in_a_bank(gpu_lib, oracle_mod):
                 if c == 2 and (k == 0 or not patterns[c][k] or not patterns[c][k - 1]):
                     continue  # NFM on noise alone (never gated here: its PLL wanders) or re-acquiring behind it: compared once locked
                     # (see test_bank_with_every_narrow_demod_mode)
-                bar = TOL_AGC_STARTUP if c == 0 else (2e-5 if c == 2 else TOL)
+                bar = TOL_AGC_STARTUP if c == 0 else TOL
                 assert rel_rms(g, want[c][k]) <= bar, "channel %d super-frame %d" % (c, k)
     assert opened >= 12
 
