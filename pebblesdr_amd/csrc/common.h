@@ -60,6 +60,22 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b)  // a * conj(b)
     const v2f_t d = __builtin_elementwise_fma(bx, av, nb * as);
     return make_float2(d.x, d.y);
 }
+// c * x and acc + c * x in two packed instructions with c as it lies in its register pair: the broadcasts and the half
+// negation are operand modifiers.  (The compiler's own cmul materialises {c.x, c.x} and {-c.y, c.y} -- two more register pairs
+// per loop-invariant constant, or two more instructions per product when c varies.)
+__device__ __forceinline__ v2f_t cmul_pk(v2f_t c, v2f_t x)
+{
+    v2f_t r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(r) : "v"(c), "v"(x));  // (-c.y x.y, c.y x.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(r) : "v"(c), "v"(x));                       // + (c.x x.x, c.x x.y)
+    return r;
+}
+__device__ __forceinline__ v2f_t cmac_pk(v2f_t acc, v2f_t c, v2f_t x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(c), "v"(x));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(c), "v"(x));
+    return acc;
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return a * make_float2(s, s); }

@@ -7,30 +7,43 @@
 // Fs/S: 268 MB each way for 256 channels x 0.5 M samples, 15x the bytes the call has to move (4 MB in, 34 MB out), and both
 // kernels sat on that buffer.  Here nothing above the demodulator rate is written.
 //
-// Mapping: the lanes of a wave are 64 channels of the bank (as in k_mix_hb11_bank<UNIFORM>): the input window is the same
-// address in every lane, so it is fetched with scalar loads, and a lane walks ITS channel through time: per block of 8
-// first-stage outputs it computes them in the oscillator-factored form of k_mix_hb11_lean
+// Mapping: the lanes of a wave are 64 channels of the bank (as in k_mix_hb11_bank<UNIFORM>) and a lane walks ITS channel
+// through time in blocks of 8 first-stage outputs, computed in the oscillator-factored form of k_mix_hb11_lean
 //     y0[j] = pa(j) * sum_d (h[d] step[d]) x[S j - 10 + d],   pa(j) = a_inf e^{j 2 pi (phase0 + (S j - 9) inc)}
-// and pushes each one, as it appears, through the three halfbands held ENTIRELY IN REGISTERS in transposed form: a stage
-// keeps the partial sums of its PENDING outputs instead of its past inputs,
+// and pushed, as they appear, through the three halfbands held ENTIRELY IN REGISTERS in transposed form: a stage keeps the
+// partial sums of its PENDING outputs instead of its past inputs,
 //     y[m] = sum_p h[p] x[2m - (T-1) + p]:  an even-indexed input adds h[p] x to the (T+1)/2 outputs it reaches through the
 //     even taps (the first of them starts there, the last is completed by it and moves on to the next stage); an
 //     odd-indexed input meets only the centre tap (T = 4k + 3)
-// -- 11 + 11 + 16 running sums for 15/19/31 taps (76 registers; the stored-input form needs 146), every index static, and
-// 31 register moves per block to re-base them.  No barrier and no memory traffic inside the loop except the block's input
-// window (below); a wave's 16 x 64 results leave through a wave-private LDS tile as whole 128-byte row segments
-// (front_store_rows' layout).
+// -- 11 + 11 + 16 running sums for 15/19/31 taps (76 registers; the stored-input form needs 146), every index static.
 //
-// Time is cut into chunks of L final outputs, one wave each.  A chunk cannot inherit the registers of the wave before it,
-// so it first runs `warm` = halo / 8 blocks whose results it throws away (halo = (T1-1) + 2 (T2-1) + 4 (T3-1) first-stage
-// outputs is the look-back of the cascade: 170 -> 21 blocks for 15/19/31); after them every carried value is exact.  Chunk 0
-// of a call takes its warm-up first-stage outputs from the previous call's tail (the stage-0 buffer's head-room, which
-// this kernel also refreshes -- through a small staging buffer, because chunk 0 of the same launch still reads the old
-// one -- together with the mixed-sample history of the two-kernel route, so a call can go either way: the host sends
-// calls inside an oscillator's amplitude transient down the two-kernel route).
+// A chunk of L final outputs is the work of a THREE-WAVE workgroup: waves 0 and 1 produce a block's first-stage outputs 0..3
+// and 4..7 into an LDS ring, wave 2 feeds them through the halfbands one block behind, one workgroup barrier per block.  (One
+// wave per chunk doing all of it ran the bank as 1024 lone waves; counters: VALU active 49 % of a wave's life, 0.138 ms per
+// configs[2] call against 0.105 for the pipeline.)  The raw samples a block needs, x[S (8 o - 7) - 10 ...] (7 S + 11 of them),
+// are the same for every lane: wave 0 fetches them with ONE coalesced vector load per 64 samples (lane = sample), two blocks
+// ahead, parks them in an LDS window and the producers read the taps at the same address in every lane.  (Scalar loads did
+// this without LDS, but a wave then waited out a scalar-cache miss per output.)  The rotation from output to output inside
+// a producer's four is folded into its 28 complex tap constants, and the complex products are two packed instructions each
+// with the half-negation as an operand modifier (common.h cmac_pk).  The chunk's results leave through an LDS tile as whole
+// 128-byte row segments (front_store_rows' layout).
 //
-// Bound: fp32 VALU (~27 packed operations per first-stage output per lane); HBM traffic is the compulsory 8 B per input
-// sample per stream + 8 B per final output per channel.
+// A chunk cannot inherit the registers of the chunk before it, so it first runs `warm` = halo / 8 blocks whose results it
+// throws away (halo = (T1-1) + 2 (T2-1) + 4 (T3-1) first-stage outputs is the look-back of the cascade: 170 -> 21 blocks for
+// 15/19/31); after them every carried value is exact.  Chunk 0 of a call takes its warm-up first-stage outputs from the
+// previous call's tail (the stage-0 buffer's head-room, which this kernel also refreshes -- through a small staging buffer,
+// because chunk 0 of the same launch still reads the old one -- together with the mixed-sample history of the two-kernel
+// route, so a call can go either way: the host sends calls inside an oscillator's amplitude transient down the two-kernel
+// route).
+//
+// Bound: fp32 VALU issue (v_pk_fma_f32 retires one per ~5.2 clocks per SIMD whatever the occupancy; ~340 packed
+// operations per block of 8 x 64 first-stage outputs over the three waves, 25 % of them warm-up at L = 64); the broadcast
+// window reads cost their full 64 x 16 bytes of LDS bandwidth each and come second.  HBM traffic is the compulsory 8 B per
+// input sample per stream + 8 B per final output per channel (measured 2.8x that: the window fetches of the warm-up blocks).
+// Measured alternative (round 2, not kept): first stage with the lanes along TIME (raw samples per lane, channel constants
+// scalar, the hb11's symmetry halving its arithmetic) transposed to this layout through a 64 x 64 LDS tile, ten waves per
+// workgroup -- parity-clean but 0.143 ms: its 78 KB of LDS admit one workgroup per CU and the halfband wave, alone on its
+// SIMD, needs ~760 clocks per block (profiles/README.md).
 #pragma once
 #include "kernels_frontend.h"
 #include "params.h"
@@ -69,37 +82,43 @@ struct FusedDecGeom {
 // x_hist: [>= 16] raw input samples preceding the call (x[-16 .. -1]); xh_out receives the call's last 16.
 // y0_hist: data pointer of the stage-0 history rows: y0_hist[c * y0_pitch - HY .. -1] = previous call's last HY first-stage outputs.
 // y0_stage: [C][HY] receives this call's last HY first-stage outputs (the host's tail refresh copies them into the head-room).
-// grid (ceil(chunks / 4), ceil(C / 64)), block 256 = four independent waves (four consecutive chunks).
-template <int T1, int T2, int T3>
-static __global__ __launch_bounds__(256, 2) void k_mix_dec_fused(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                                 const ChanOsc *__restrict__ osc, OscDynInline dyn,
-                                                                 const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
-                                                                 const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,
-                                                                 float2 *__restrict__ mixed_hist_out, FusedDecParams P)
+// SFIX: the first-stage stride as a compile-time constant (the producers' window becomes twelve 16-byte reads), 0: P.S.
+// grid (chunks, ceil(C / 64)), block 192.
+template <int T1, int T2, int T3, int SFIX>
+static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                            const ChanOsc *__restrict__ osc, OscDynInline dyn,
+                                                            const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
+                                                            const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,
+                                                            float2 *__restrict__ mixed_hist_out, FusedDecParams P)
 {
     using G = FusedDecGeom<T1, T2, T3>;
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY;
-    constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;  // centre taps
-    constexpr int XB = 128;  // samples per window buffer: a block's raw span is 7 S + 11 <= 123 for S <= 16
-    __shared__ float2 tiles[4][16 * 65];
-    __shared__ float2 xwin[4][2][XB];
-    __shared__ float2 htile[4][8 * 65];  // a block's eight first-stage outputs x 64 channels on their way to the history rows
+    constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
+    constexpr int XB = 128;
+    __shared__ float2 tile[16 * 65];
+    __shared__ __attribute__((aligned(16))) float2 xwin[2][XB];
+    __shared__ float4 ring[2][4 * 64];   // [block parity][output pair][channel lane]
+    __shared__ float2 htile[8 * 65];
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float2 *tile = tiles[wv];
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0, 1: first-stage outputs 0..3 / 4..7; 2: the halfbands
     const int cbase = blockIdx.y * 64;
     const bool live = cbase + lane < P.n_chan;
     const int c = live ? cbase + lane : P.n_chan - 1;
-    const int S = P.S;
-    const long long chunk = (long long)blockIdx.x * 4 + wv;
-    const long long o0 = chunk * P.L;
-    if (o0 >= P.n_out) return;  // wave-uniform
+    const int S = SFIX ? SFIX : P.S;
+    const long long o0 = (long long)blockIdx.x * P.L;
+    if (o0 >= P.n_out) return;  // workgroup-uniform
     const long long o1 = o0 + P.L < P.n_out ? o0 + P.L : P.n_out;
     const bool last_chunk = o1 == P.n_out;
-    const long long len0 = 8 * P.n_out;      // first-stage outputs of the call
+    const long long len0 = 8 * P.n_out;
     const long long n_in = (long long)S * len0;
+    const long long o_start = o0 - G::warm;
+    const long long o_end = last_chunk ? o1 + 1 : o1;  // the last chunk runs one more block (o == n_out) whose first-stage outputs only feed the history
+    const long long ob0 = o_start >= 0 ? o_start : 0;
+    const int nb = (int)(o_end - o_start);
+    const int n_iter = nb + 1;            // the halfbands run one block behind
+    const int it0 = (int)(ob0 - o_start);  // the first iteration that produces (chunk 0's warm-up blocks come from the history)
+    const float2 *yh = y0_hist + (long long)c * P.y0_pitch;
 
-    // ---- per-channel constants ----
     const ChanOsc *oc = &osc[c];
     const double inc = oc->inc;
     double phase0 = oc->phase0;
@@ -110,20 +129,157 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_fused(const float2 *_
             if (c == k) { phase0 = dyn.d[k].phase0; mix_on = dyn.d[k].mix_on; }
     }
     const bool mix = mix_on != 0;
-    // c_d = h[d] * step[d] for the window's used samples d = 0 2 4 5 6 8 10 (c_0 is real: step[0] = 1)
-    float2 c2 = make_float2(hb_tap<11>(2), 0.f), c4 = make_float2(hb_tap<11>(4), 0.f), c5 = make_float2(hb_tap<11>(5), 0.f), c6 = make_float2(hb_tap<11>(6), 0.f),
-           c8 = make_float2(hb_tap<11>(8), 0.f), c10 = make_float2(hb_tap<11>(10), 0.f);
-    float2 rot = make_float2(1.f, 0.f), rot8 = make_float2(1.f, 0.f);
-    if (mix) {
-        c2 = cscale(oc->step[2], hb_tap<11>(2)); c4 = cscale(oc->step[4], hb_tap<11>(4)); c5 = cscale(oc->step[5], hb_tap<11>(5));
-        c6 = cscale(oc->step[6], hb_tap<11>(6)); c8 = cscale(oc->step[8], hb_tap<11>(8)); c10 = cscale(oc->step[10], hb_tap<11>(10));
-        rot = cis_cycles((double)S * inc);        // one first-stage output to the next
-        rot8 = cis_cycles((double)(8 * S) * inc); // one block to the next
-    }
-    const float h00 = hb_tap<11>(0);
-    const float amp = mix ? P.a_inf * P.gain0 : P.gain0;  // f == 0: the mixer returns its input untouched (mixer.cpp:51-53)
 
-    // running sums: a1[i] <-> y1[4 o - 3 + i], a2[i] <-> y2[2 o - 1 + i], a3[i] <-> y3[o + i] at the start of block o
+    if (role < 2) {
+        // ------------------------------ producers ------------------------------
+        // ck[k][t] = h[d_t] step[d_t] rot^k, d_t = 0 2 4 5 6 8 10: the rotation from output to output inside a wave's four is
+        // folded into the constants (28 register pairs; the producers have them to spare -- the halfbands set the kernel's budget)
+        const float amp = mix ? P.a_inf * P.gain0 : P.gain0;
+        v2f_t ck[4][7];
+        v2f_t rot8 = {1.f, 0.f};
+        {
+            constexpr int dt[7] = {0, 2, 4, 5, 6, 8, 10};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float2 rk = mix ? cis_cycles((double)(k * S) * inc) : make_float2(1.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const float hd = dt[q] == 0 ? hb_tap<11>(0) : dt[q] == 2 ? hb_tap<11>(2) : dt[q] == 4 ? hb_tap<11>(4) : dt[q] == 5 ? hb_tap<11>(5)
+                                   : dt[q] == 6 ? hb_tap<11>(6) : dt[q] == 8 ? hb_tap<11>(8) : hb_tap<11>(10);
+                    float2 cd = make_float2(hd, 0.f);
+                    if (mix && dt[q] != 0) cd = cscale(oc->step[dt[q]], hd);
+                    const float2 v = cmul(rk, cd);
+                    ck[k][q] = v2f_t{v.x, v.y};
+                }
+            }
+            if (mix) {
+                const float2 r8 = cis_cycles((double)(8 * S) * inc);
+                rot8 = v2f_t{r8.x, r8.y};
+            }
+        }
+        const int k0 = 4 * role;  // this wave's outputs of a block: k0 .. k0 + 3
+        const int nl = 7 * S + 11 > 64 ? 2 : 1;
+        // ONE load per 64 samples whatever the block (samples before the call's start come from the previous call's tail;
+        // lanes before that tail or past the end load a valid address and are never read): with a fixed number of loads per
+        // fetch the compiler can count, and the wait before a park leaves the younger fetch in flight
+        auto fetch = [&](long long o, float2 (&r)[2]) {
+            const long long b = (long long)S * (8 * o - 7) - 10;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (q < nl) {
+                    long long i = b + lane + 64 * q;
+                    i = i < n_in ? i : n_in - 1;
+                    const float2 *p = i >= 0 ? in + i : x_hist + (i >= -16 ? 16 + i : 0);
+                    r[q] = *p;
+                }
+            }
+        };
+        // two windows in flight, in two register sets that swap roles from block to block (the loop is unrolled by two: a
+        // register move would have to wait for the load it moves)
+        float2 xn[2], xn2[2];
+        auto park = [&](long long o, const float2 (&r)[2]) {
+            xwin[o & 1][lane] = r[0];
+            if (nl > 1) xwin[o & 1][lane + 64] = r[1];
+        };
+        if (role == 0) {
+            fetch(ob0, xn);
+            park(ob0, xn);
+            fetch(ob0 + 1, xn);
+            fetch(ob0 + 2, xn2);
+        }
+        __syncthreads();
+        v2f_t pa_blk = {amp, 0.f};
+        // one block; FEEDER (wave 0) also parks block o + 1's window (the buffer the block before this one read) and starts
+        // the fetch of block o + 3 into the registers that held it.  No condition around the fetch, and one copy of the loop per
+        // role: only then does the compiler know that exactly one younger load is in flight when it waits for the parked one.
+        auto produce = [&](auto feeder, long long o, float2 (&xq)[2]) {
+            const float2 *xw = xwin[o & 1] + S * k0;  // this wave's first window
+            const long long j0 = 8 * o - 7;
+            if (((o - o_start) & 7) == 0 || o == 0) {
+                // exact phase every eighth block (each producer for its own first output), a constant rotation in between
+                if (mix) {
+                    const float2 e = cscale(cis_cycles(phase0 + (double)((long long)S * (j0 + k0) - 9) * inc), amp);
+                    pa_blk = v2f_t{e.x, e.y};
+                }
+            } else {
+                pa_blk = cmul_pk(rot8, pa_blk);
+            }
+            // the four windows x[S k + d]: at S = 4 they are 23 consecutive samples (twelve 16-byte broadcast reads)
+            v2f_t xs[4][7];
+            if (SFIX == 4) {
+                float4 x4[12];
+#pragma unroll
+                for (int m = 0; m < 12; m++) x4[m] = reinterpret_cast<const float4 *>(xw)[m];
+                constexpr int dt[7] = {0, 2, 4, 5, 6, 8, 10};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        const int i = 4 * k + dt[q];
+                        xs[k][q] = (i & 1) ? v2f_t{x4[i / 2].z, x4[i / 2].w} : v2f_t{x4[i / 2].x, x4[i / 2].y};
+                    }
+            } else {
+                constexpr int dt[7] = {0, 2, 4, 5, 6, 8, 10};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        const float2 v = xw[S * k + dt[q]];
+                        xs[k][q] = v2f_t{v.x, v.y};
+                    }
+            }
+            // two chains per output (taps 0 4 6 10 | 2 5 8), four outputs: eight independent chains for the issue slots
+            v2f_t y[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v2f_t ea = cmul_pk(ck[k][0], xs[k][0]);
+                v2f_t eb = cmul_pk(ck[k][1], xs[k][1]);
+                ea = cmac_pk(ea, ck[k][2], xs[k][2]);
+                eb = cmac_pk(eb, ck[k][3], xs[k][3]);
+                ea = cmac_pk(ea, ck[k][4], xs[k][4]);
+                eb = cmac_pk(eb, ck[k][5], xs[k][5]);
+                ea = cmac_pk(ea, ck[k][6], xs[k][6]);
+                y[k] = cmul_pk(pa_blk, ea + eb);
+            }
+            float4 *rg = ring[o & 1] + (k0 / 2) * 64 + lane;
+            rg[0] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+            rg[64] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+            if (decltype(feeder)::value) {
+                park(o + 1, xq);
+                fetch(o + 3, xq);
+            }
+            __syncthreads();
+        };
+        auto run = [&](auto feeder) {
+            int it = 0;
+            for (; it < it0; it++) __syncthreads();
+            for (; it + 1 < nb; it += 2) {
+                produce(feeder, o_start + it, xn);
+                produce(feeder, o_start + it + 1, xn2);
+            }
+            if (it < nb) produce(feeder, o_start + it, xn);
+            __syncthreads();  // (the halfbands' last block)
+        };
+        if (role == 0) run(std::true_type{});
+        else run(std::false_type{});
+        if (last_chunk) {
+            // the next call's raw-input tail and, for the two-kernel route, the mixed-sample history m[n-10 .. n-1] (each with its exact phase)
+            if (role == 0 && blockIdx.y == 0 && lane < 16) xh_out[lane] = in[n_in - 16 + lane];
+            if (role == 1 && live && mixed_hist_out != nullptr) {
+                float2 *hp = mixed_hist_out + (long long)c * P.hist_pitch;
+#pragma unroll 1
+                for (int q = 0; q < 10; q++) {
+                    const long long i = n_in - 10 + q;
+                    float2 v = in[i];
+                    if (mix) v = cmul(cscale(cis_cycles(phase0 + (double)(i + 1) * inc), P.a_inf), v);
+                    hp[q] = v;
+                }
+            }
+        }
+        return;
+    }
+
+    // ------------------------------ consumer: the halfbands, one block behind ------------------------------
     float2 a1[N1], a2[N2], a3[N3];
 #pragma unroll
     for (int i = 0; i < N1; i++) a1[i] = make_float2(0.f, 0.f);
@@ -131,55 +287,10 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_fused(const float2 *_
     for (int i = 0; i < N2; i++) a2[i] = make_float2(0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < N3; i++) a3[i] = make_float2(0.f, 0.f);
-
-    const float2 *yh = y0_hist + (long long)c * P.y0_pitch;  // yh[j], j in [-HY, -1]
-    float2 *ys = y0_stage + (long long)c * HY;
-    const long long o_start = o0 - G::warm;
-    // the last chunk runs one block more: first-stage outputs 8 n_out - 7 .. 8 n_out - 1 belong to no output of this call but
-    // to the next call's history
-    const long long o_end = last_chunk ? o1 + 1 : o1;
-    float2 pa_blk = make_float2(amp, 0.f);
-
-    // The raw samples a block needs, x[S (8 o - 7) - 10 ...] (7 S + 11 of them), are the same for every lane: the wave fetches
-    // them one block ahead with ONE coalesced vector load per 64 samples (lane = sample; samples before the call's start come
-    // from the previous call's tail), parks them in its own LDS window and every lane then reads the taps at the same
-    // addresses (broadcast reads).  Scalar loads did this without LDS, but a wave then waited out a scalar-cache miss per
-    // output: 5000 clocks per block against ~1400 of arithmetic.
-    const int nl = 7 * S + 11 > 64 ? 2 : 1;
-    auto fetch = [&](long long o, float2 (&r)[2]) {
-        const long long b = (long long)S * (8 * o - 7) - 10;
-        if (b >= 0 && b + 128 <= n_in) {  // wave-uniform: the whole span lies inside the call (all but the edge blocks)
-            r[0] = in[b + lane];
-            if (nl > 1) r[1] = in[b + lane + 64];
-            return;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (q < nl) {
-                long long i = b + lane + 64 * q;
-                i = i < n_in ? i : n_in - 1;
-                r[q] = i < 0 ? (i >= -16 ? x_hist[16 + i] : make_float2(0.f, 0.f)) : in[i];
-            }
-        }
-    };
-    // window pipeline: block o's samples are fetched during block o - 2 (registers), parked in LDS in the middle of block
-    // o - 1 (the buffer block o - 2 read) and read back tap by tap during block o: a fetch has a whole block to land
-    const long long ob0 = o_start >= 0 ? o_start : 0;  // blocks before the call's start take their first-stage outputs from the history
-    float2 xn[2];
-    auto park = [&](long long o) {
-        xwin[wv][o & 1][lane] = xn[0];
-        if (nl > 1) xwin[wv][o & 1][lane + 64] = xn[1];
-    };
-    fetch(ob0, xn);
-    park(ob0);
-    fetch(ob0 + 1, xn);
-    wave_sync();
-
     float2 y3 = make_float2(0.f, 0.f);
-    // first-stage output number k of a block (j = 8 o - 7 + k) enters the cascade; k is a constant after unrolling
     auto feed = [&](int k, float2 y0) {
         auto bc = [](float h) { return make_float2(h, h); };
-        if (k & 1) {  // j even: the even taps of stage 1; y1[4 o - 3 + b] is complete
+        if (k & 1) {
             const int b = (k - 1) / 2;
 #pragma unroll
             for (int t = 0; t < (T1 + 1) / 2; t++) {
@@ -187,7 +298,7 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_fused(const float2 *_
                 a1[b + t] = t == (T1 + 1) / 2 - 1 ? v : a1[b + t] + v;
             }
             const float2 y1 = a1[b];
-            if (b & 1) {  // m even
+            if (b & 1) {
                 const int b2 = (b - 1) / 2;
 #pragma unroll
                 for (int t = 0; t < (T2 + 1) / 2; t++) {
@@ -195,7 +306,7 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_fused(const float2 *_
                     a2[b2 + t] = t == (T2 + 1) / 2 - 1 ? v : a2[b2 + t] + v;
                 }
                 const float2 y2 = a2[b2];
-                if (b2 & 1) {  // q even: y3[o] is complete
+                if (b2 & 1) {
 #pragma unroll
                     for (int t = 0; t < (T3 + 1) / 2; t++) {
                         const float2 v = y2 * bc(hb_tap<T3>(T3 - 1 - 2 * t));
@@ -212,126 +323,74 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_fused(const float2 *_
             a1[(k + PC1 - 1) / 2] = a1[(k + PC1 - 1) / 2] + y0 * bc(hb_tap<T1>(PC1));
         }
     };
-
-    struct Win { float2 x0, x2, x6, x8, x10; float4 x45; };
-    // window of a block's output k: xw[S k + d], d = 0 2 4 5 6 8 10
-    auto read_win = [&](const float2 *xw, int k) {
-        const float2 *p = xw + S * k;
-        Win w;
-        w.x0 = p[0]; w.x2 = p[2]; w.x6 = p[6]; w.x8 = p[8]; w.x10 = p[10];
-        w.x45 = *reinterpret_cast<const float4 *>(p + 4);
-        return w;
-    };
-    auto stage0 = [&](const Win &w, float2 pa) {
-        // a tree, not a chain: six dependent additions in a row leave a lone wave nothing to issue between them
-        const float2 t0 = cadd(cscale(w.x0, h00), cmul(c2, w.x2));
-        const float2 t1 = cadd(cmul(c4, make_float2(w.x45.x, w.x45.y)), cmul(c5, make_float2(w.x45.z, w.x45.w)));
-        const float2 t2 = cadd(cmul(c6, w.x6), cmul(c8, w.x8));
-        const float2 acc = cadd(cadd(t0, t1), cadd(t2, cmul(c10, w.x10)));
-        return cmul(pa, acc);
-    };
-
-    for (long long o = o_start; o < o_end; o++) {  // wave-uniform
-        const float2 *xw = xwin[wv][o & 1];
-        // in the middle of block o (o >= ob0): park block o + 1's samples, start fetching block o + 2's
-        auto advance = [&]() {
-            if (o >= ob0) {
-                park(o + 1);
-                wave_sync();
-                fetch(o + 2, xn);
-            }
-        };
-        // ---- the block's eight first-stage outputs j = 8 o - 7 .. 8 o ----
-        const long long j0 = 8 * o - 7;
-        if (o < 0) {  // chunk 0's warm-up: the previous call's tail
+    __syncthreads();  // (the producers' prologue barrier)
+    for (int it = 0; it < n_iter; it++) {
+        const long long o = o_start + it - 1;  // the block consumed in this iteration
+        if (it >= 1 && it <= nb) {
+            const long long j0 = 8 * o - 7;
+            float2 y0[8];
+            if (o <= 0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) feed(k, yh[j0 + k]);
-            advance();
-        } else {
-            if (((o - o_start) & 7) == 0 || o == 0) {
-                // exact phase every eighth block, a constant rotation in between (and from output to output inside a block)
-                if (mix) pa_blk = cscale(cis_cycles(phase0 + (double)((long long)S * j0 - 9) * inc), amp);
-            } else {
-                pa_blk = cmul(rot8, pa_blk);  // (1, 0) for a channel that does not mix
-            }
-            float2 pa = pa_blk;
-            const bool keep = last_chunk && j0 + 7 >= len0 - HY;  // among the call's last HY: the next call's history
-            if (o == 0) {  // block 0: only output 0 is new, the seven before it are the previous call's
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    float2 y0 = stage0(read_win(xw, k), pa);
-                    pa = cmul(rot, pa);
-                    if (k < 7) y0 = yh[j0 + k];
-                    if (keep) htile[wv][k * 65 + lane] = y0;
-                    feed(k, y0);
-                    sched_fence();
-                    if (k == 3) advance();
+                for (int k = 0; k < 7; k++) y0[k] = yh[j0 + k];  // chunk 0's warm-up: the previous call's tail (block 0: only output 0 is new)
+                if (o < 0) {
+                    y0[7] = yh[j0 + 7];
+                } else {
+                    const float4 v = ring[0][3 * 64 + lane];
+                    y0[7] = make_float2(v.z, v.w);
                 }
             } else {
-                // the window of output k + 1 is read while output k is computed
-                Win w = read_win(xw, 0);
+                const float4 *rg = ring[o & 1] + lane;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    Win wn = w;
-                    if (k < 7) wn = read_win(xw, k + 1);
-                    const float2 y0 = stage0(w, pa);
-                    pa = cmul(rot, pa);
-                    if (keep) htile[wv][k * 65 + lane] = y0;
-                    feed(k, y0);
-                    w = wn;
-                    sched_fence();  // one window ahead, not eight: the scheduler otherwise hoists them all (spills)
-                    if (k == 3) advance();
+                for (int k = 0; k < 4; k++) {
+                    const float4 v = rg[k * 64];
+                    y0[2 * k] = make_float2(v.x, v.y);
+                    y0[2 * k + 1] = make_float2(v.z, v.w);
                 }
             }
-            if (keep) {  // eight outputs x 64 channels -> 64-byte row segments of the staging rows
-                wave_sync();
+            const bool keep = last_chunk && o >= 0 && j0 + 7 >= len0 - HY;
+            if (keep) {  // eight outputs x 64 channels -> 64-byte row segments of the history staging rows
 #pragma unroll
-                for (int it = 0; it < 8; it++) {
-                    const int idx = it * 64 + lane;
+                for (int k = 0; k < 8; k++) htile[k * 65 + lane] = y0[k];
+                wave_sync();
+#pragma unroll 1
+                for (int i8 = 0; i8 < 8; i8++) {
+                    const int idx = i8 * 64 + lane;
                     const int ch = idx >> 3, k = idx & 7;
                     const long long j = j0 + k;
                     if (cbase + ch < P.n_chan && j >= len0 - HY && j < len0)
-                        y0_stage[(long long)(cbase + ch) * HY + (j - (len0 - HY))] = htile[wv][k * 65 + ch];
+                        y0_stage[(long long)(cbase + ch) * HY + (j - (len0 - HY))] = htile[k * 65 + ch];
                 }
                 wave_sync();
             }
-        }
-        if (o >= o0 && o < o1) {
-            const int jt = (int)(o - o0) & 15;
-            tile[jt * 65 + lane] = cscale(y3, P.gain);
-            if (jt == 15 || o == o1 - 1) {  // 16 outputs x 64 channels -> whole 128-byte row segments
-                const long long ob = o - jt;
-                wave_sync();
+            if (o != P.n_out) {
 #pragma unroll
-                for (int it = 0; it < 16; it++) {
-                    const int idx = it * 64 + lane;
-                    const int ch = idx >> 4, t = idx & 15;
-                    if (cbase + ch < P.n_chan && t <= jt) out[(long long)(cbase + ch) * P.out_pitch + ob + t] = tile[t * 65 + ch];
+                for (int k = 0; k < 8; k++) {
+                    feed(k, y0[k]);
                 }
-                wave_sync();
+                if (o >= o0 && o < o1) {
+                    const int jt = (int)(o - o0) & 15;
+                    tile[jt * 65 + lane] = cscale(y3, P.gain);
+                    if (jt == 15 || o == o1 - 1) {
+                        const long long ob = o - jt;
+                        wave_sync();
+#pragma unroll 1  // (unrolled, the sixteen row pointers are carried, and stepped, through every block)
+                        for (int i16 = 0; i16 < 16; i16++) {
+                            const int idx = i16 * 64 + lane;
+                            const int ch = idx >> 4, t = idx & 15;
+                            if (cbase + ch < P.n_chan && t <= jt) out[(long long)(cbase + ch) * P.out_pitch + ob + t] = tile[t * 65 + ch];
+                        }
+                        wave_sync();
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i + 4 < N1; i++) a1[i] = a1[i + 4];
+#pragma unroll
+                for (int i = 0; i + 2 < N2; i++) a2[i] = a2[i + 2];
+#pragma unroll
+                for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
             }
         }
-        // ---- re-base the running sums on the next block ----
-#pragma unroll
-        for (int i = 0; i + 4 < N1; i++) a1[i] = a1[i + 4];
-#pragma unroll
-        for (int i = 0; i + 2 < N2; i++) a2[i] = a2[i + 2];
-#pragma unroll
-        for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
-    }
-    if (last_chunk) {
-        // the next call's raw-input tail and, for the two-kernel route, the mixed-sample history m[n-10 .. n-1] (each with its exact phase)
-        if (blockIdx.y == 0 && lane < 16) xh_out[lane] = in[n_in - 16 + lane];
-        if (live && mixed_hist_out != nullptr) {
-            float2 *hp = mixed_hist_out + (long long)c * P.hist_pitch;
-#pragma unroll 1
-            for (int q = 0; q < 10; q++) {
-                const long long i = n_in - 10 + q;
-                float2 v = in[i];
-                if (mix) v = cmul(cscale(cis_cycles(phase0 + (double)(i + 1) * inc), P.a_inf), v);
-                hp[q] = v;
-            }
-        }
+        __syncthreads();
     }
 }
 

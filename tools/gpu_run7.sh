@@ -1,3 +1,5 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r02_t7.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/r02_t7.log
-PEBBLEGPU_SPECTRUM_SHARED=1 timeout -k 10 600 python3 bench.py > gpurun_out/r02_bench7.json 2> gpurun_out/r02_bench7.err; echo "bench rc=$?"; tail -3 gpurun_out/r02_bench7.err; cat gpurun_out/r02_bench7.json
+cp build_exp/lib_TIMING.so pebblesdr_amd/libpebblegpu.so
+PEBBLEGPU_FUSED_L=256 timeout -k 10 120 python3 tools/pmc_bank.py 2 > gpurun_out/tp_timing_256.txt 2>&1
+PEBBLEGPU_FUSED_L=128 timeout -k 10 120 python3 tools/pmc_bank.py 2 > gpurun_out/tp_timing_128.txt 2>&1
+wc -l gpurun_out/tp_timing_*.txt
