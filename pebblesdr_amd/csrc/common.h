@@ -70,6 +70,22 @@ __device__ __forceinline__ v2f_t cmul_pk(v2f_t c, v2f_t x)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(r) : "v"(c), "v"(x));                       // + (c.x x.x, c.x x.y)
     return r;
 }
+// acc + c.x * v and acc + c.y * v (a real coefficient out of either half of a register pair, broadcast by the operand selects)
+__device__ __forceinline__ v2f_t fma_lo_pk(v2f_t acc, v2f_t c, v2f_t v)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(c), "v"(v));
+    return acc;
+}
+__device__ __forceinline__ v2f_t fma_hi_pk(v2f_t acc, v2f_t c, v2f_t v)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(c), "v"(v));
+    return acc;
+}
+__device__ __forceinline__ float2 cmul_pk(float2 c, float2 x)
+{
+    const v2f_t r = cmul_pk(v2f_t{c.x, c.y}, v2f_t{x.x, x.y});
+    return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ v2f_t cmac_pk(v2f_t acc, v2f_t c, v2f_t x)
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(c), "v"(x));

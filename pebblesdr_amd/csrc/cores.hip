@@ -441,14 +441,14 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             if (fused_L < 16) fused_L = -1;  // choose per call
             fused_L &= ~15;
         }
-        long long L = fused_L > 0 ? fused_L : ((len_out * groups / 1024 + 15) & ~15LL);  // ~1024 three-wave workgroups (four per CU); every chunk pays a warm-up
+        long long L = fused_L > 0 ? fused_L : ((len_out * groups / 704 + 15) & ~15LL);  // ~700 four-wave workgroups (measured best on 256 CUs: 96 for configs[2]); every chunk pays a 21-block warm-up
         if (L < 32) L = 32;
         fused_p->n_out = len_out;
         fused_p->out_pitch = fin.pitch;
         fused_p->y0_pitch = buf0.pitch;
         fused_p->L = (int)L;
         fused_p->a_inf = osc.a_inf;
-        launch(first.stride == 4 ? k_mix_dec_fused<15, 19, 31, 4> : k_mix_dec_fused<15, 19, 31, 0>, dim3(cdiv(len_out, L), (unsigned)groups), dim3(192), s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn,
+        launch(k_mix_dec_fused<15, 19, 31>, dim3(cdiv(len_out, L), (unsigned)groups), dim3(256), s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn,
                (const float2 *)d_xhist[hist_parity], d_xhist[hist_parity ^ 1], (const float2 *)buf0.data(), d_y0stage, d_hist_mixed[hist_parity ^ 1], *fused_p);
         PG_HIP(hipGetLastError());
         hist_parity ^= 1;

@@ -61,7 +61,7 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
             for (int m = 0; m < 16; m++) x[m] = rp[136 * m];
         }
         sync();  // every gather done before anyone scatters into the same image
-        const float2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+        const float2 w3 = cmul_pk(w1, w2), w5 = cmul_pk(w4, w1), w6 = cmul_pk(w4, w2), w7 = cmul_pk(w4, w3);
         float2 *wbase = lds + lpad((t - k) * 8 + k);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -69,8 +69,9 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
 #pragma unroll
             for (int r = 0; r < 8; r++) u[r] = x[q + 2 * r];
             if (DO_MATH) {
-                u[1] = cmul(w1, u[1]); u[2] = cmul(w2, u[2]); u[3] = cmul(w3, u[3]); u[4] = cmul(w4, u[4]);
-                u[5] = cmul(w5, u[5]); u[6] = cmul(w6, u[6]); u[7] = cmul(w7, u[7]);
+                // (cmul_pk: the twiddle as it lies in its registers; cmul would build (-w.y, w.y) with two more instructions each)
+                u[1] = cmul_pk(w1, u[1]); u[2] = cmul_pk(w2, u[2]); u[3] = cmul_pk(w3, u[3]); u[4] = cmul_pk(w4, u[4]);
+                u[5] = cmul_pk(w5, u[5]); u[6] = cmul_pk(w6, u[6]); u[7] = cmul_pk(w7, u[7]);
                 bfly8<+1>(u);
             }
             float2 *wp = wbase + lpad(1024 * q);
@@ -94,12 +95,12 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
         }
         sync();  // the image may be overwritten (the caller parks its results there)
         if (!DO_MATH) return;
-        const float2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
-        x[1] = cmul(w1, x[1]); x[2] = cmul(w2, x[2]); x[3] = cmul(w3, x[3]); x[4] = cmul(w4, x[4]);
-        x[5] = cmul(w5, x[5]); x[6] = cmul(w6, x[6]); x[7] = cmul(w7, x[7]); x[8] = cmul(w8, x[8]);
-        x[9] = cmul(cmul(w8, w1), x[9]); x[10] = cmul(cmul(w8, w2), x[10]); x[11] = cmul(cmul(w8, w3), x[11]);
-        x[12] = cmul(cmul(w8, w4), x[12]); x[13] = cmul(cmul(w8, w5), x[13]); x[14] = cmul(cmul(w8, w6), x[14]);
-        x[15] = cmul(cmul(w8, w7), x[15]);
+        const float2 w3 = cmul_pk(w1, w2), w5 = cmul_pk(w4, w1), w6 = cmul_pk(w4, w2), w7 = cmul_pk(w4, w3);
+        x[1] = cmul_pk(w1, x[1]); x[2] = cmul_pk(w2, x[2]); x[3] = cmul_pk(w3, x[3]); x[4] = cmul_pk(w4, x[4]);
+        x[5] = cmul_pk(w5, x[5]); x[6] = cmul_pk(w6, x[6]); x[7] = cmul_pk(w7, x[7]); x[8] = cmul_pk(w8, x[8]);
+        x[9] = cmul_pk(cmul_pk(w8, w1), x[9]); x[10] = cmul_pk(cmul_pk(w8, w2), x[10]); x[11] = cmul_pk(cmul_pk(w8, w3), x[11]);
+        x[12] = cmul_pk(cmul_pk(w8, w4), x[12]); x[13] = cmul_pk(cmul_pk(w8, w5), x[13]); x[14] = cmul_pk(cmul_pk(w8, w6), x[14]);
+        x[15] = cmul_pk(cmul_pk(w8, w7), x[15]);
         dft16(x);
         float2 y[16];
 #pragma unroll

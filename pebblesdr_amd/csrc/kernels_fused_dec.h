@@ -17,16 +17,19 @@
 //     odd-indexed input meets only the centre tap (T = 4k + 3)
 // -- 11 + 11 + 16 running sums for 15/19/31 taps (76 registers; the stored-input form needs 146), every index static.
 //
-// A chunk of L final outputs is the work of a THREE-WAVE workgroup: waves 0 and 1 produce a block's first-stage outputs 0..3
-// and 4..7 into an LDS ring, wave 2 feeds them through the halfbands one block behind, one workgroup barrier per block.  (One
-// wave per chunk doing all of it ran the bank as 1024 lone waves; counters: VALU active 49 % of a wave's life, 0.138 ms per
-// configs[2] call against 0.105 for the pipeline.)  The raw samples a block needs, x[S (8 o - 7) - 10 ...] (7 S + 11 of them),
-// are the same for every lane: wave 0 fetches them with ONE coalesced vector load per 64 samples (lane = sample), two blocks
-// ahead, parks them in an LDS window and the producers read the taps at the same address in every lane.  (Scalar loads did
-// this without LDS, but a wave then waited out a scalar-cache miss per output.)  The rotation from output to output inside
-// a producer's four is folded into its 28 complex tap constants, and the complex products are two packed instructions each
-// with the half-negation as an operand modifier (common.h cmac_pk).  The chunk's results leave through an LDS tile as whole
-// 128-byte row segments (front_store_rows' layout).
+// A chunk of L final outputs is the work of a FOUR-WAVE workgroup, a pipeline with one workgroup barrier per block: waves 0 and 1
+// produce a block's first-stage outputs 0..3 and 4..7 into an LDS ring, wave 2 runs halfband 1 one block behind them and
+// hands its four outputs on through a second ring, wave 3 runs halfbands 2 and 3 two blocks behind and writes the results.
+// (One wave per chunk doing all of it ran the bank as 1024 lone waves: 0.138 ms per configs[2] call, VALU active 49 % of a
+// wave's life; three waves -- both halfband stages in one -- 0.094; this form 0.092.)
+// The first stage uses the hb11's symmetry: its seven taps pair up around the centre,
+//     h[5+e] (step[5+e] x[5+e] + step[5-e] x[5-e]) = step[5] h[5+e] (cos(e t) (x[5+e] + x[5-e]) + j sin(e t) (x[5+e] - x[5-e])),
+// t = 2 pi inc, e = 1 3 5, x[d] = x[S j - 10 + d], and the sums and (rotated) differences are the same for every channel:
+// wave 0 forms them once per output, two blocks ahead and straight from global memory (56 lanes = 8 outputs x 7 quantities),
+// and parks them in LDS; a producer reads its 28 at the same address in every lane and spends six packed FMAs with REAL
+// per-channel coefficients per output (fourteen in the tap-by-tap complex form: 0.102 ms).  The packed instructions take their
+// broadcasts and half-negations as operand modifiers (common.h cmul_pk, fma_lo_pk).  The chunk's results leave through an LDS
+// tile as whole 128-byte row segments (front_store_rows' layout).
 //
 // A chunk cannot inherit the registers of the chunk before it, so it first runs `warm` = halo / 8 blocks whose results it
 // throws away (halo = (T1-1) + 2 (T2-1) + 4 (T3-1) first-stage outputs is the look-back of the cascade: 170 -> 21 blocks for
@@ -36,14 +39,15 @@
 // route, so a call can go either way: the host sends calls inside an oscillator's amplitude transient down the two-kernel
 // route).
 //
-// Bound: fp32 VALU issue (v_pk_fma_f32 retires one per ~5.2 clocks per SIMD whatever the occupancy; ~340 packed
-// operations per block of 8 x 64 first-stage outputs over the three waves, 25 % of them warm-up at L = 64); the broadcast
-// window reads cost their full 64 x 16 bytes of LDS bandwidth each and come second.  HBM traffic is the compulsory 8 B per
-// input sample per stream + 8 B per final output per channel (measured 2.8x that: the window fetches of the warm-up blocks).
+// Bound: VALU issue plus LDS time, which add rather than overlap here (as in k_spectrum_t128): per block of 8 x 64
+// first-stage outputs ~310 wave instructions over the four waves (v_pk_fma_f32 retires one per ~5.2 clocks per SIMD whatever the
+// occupancy) and ~230 clocks of the CU's LDS pipe (the producers' broadcast reads cost their full 64 x 16 bytes each, a
+// 16-byte write ~13 clocks), 20-25 % of it all warm-up.  HBM traffic is the compulsory 8 B per input sample per stream + 8 B
+// per final output per channel, plus the raw samples of the warm-up blocks (L2 hits: every chunk of every 64-channel group
+// reads the same 4 MB).
 // Measured alternative (round 2, not kept): first stage with the lanes along TIME (raw samples per lane, channel constants
-// scalar, the hb11's symmetry halving its arithmetic) transposed to this layout through a 64 x 64 LDS tile, ten waves per
-// workgroup -- parity-clean but 0.143 ms: its 78 KB of LDS admit one workgroup per CU and the halfband wave, alone on its
-// SIMD, needs ~760 clocks per block (profiles/README.md).
+// scalar) transposed to this layout through a 64 x 64 LDS tile, ten waves per workgroup -- parity-clean but 0.143 ms: its
+// 78 KB of LDS admit one workgroup per CU and the halfband wave, alone on its SIMD, needs ~760 clocks per block.
 #pragma once
 #include "kernels_frontend.h"
 #include "params.h"
@@ -82,10 +86,9 @@ struct FusedDecGeom {
 // x_hist: [>= 16] raw input samples preceding the call (x[-16 .. -1]); xh_out receives the call's last 16.
 // y0_hist: data pointer of the stage-0 history rows: y0_hist[c * y0_pitch - HY .. -1] = previous call's last HY first-stage outputs.
 // y0_stage: [C][HY] receives this call's last HY first-stage outputs (the host's tail refresh copies them into the head-room).
-// SFIX: the first-stage stride as a compile-time constant (the producers' window becomes twelve 16-byte reads), 0: P.S.
-// grid (chunks, ceil(C / 64)), block 192.
-template <int T1, int T2, int T3, int SFIX>
-static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__restrict__ in, float2 *__restrict__ out,
+// grid (chunks, ceil(C / 64)), block 256.
+template <int T1, int T2, int T3>
+static __global__ __launch_bounds__(256) void k_mix_dec_fused(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                             const ChanOsc *__restrict__ osc, OscDynInline dyn,
                                                             const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
                                                             const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,
@@ -94,17 +97,17 @@ static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__re
     using G = FusedDecGeom<T1, T2, T3>;
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY;
     constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
-    constexpr int XB = 128;
     __shared__ float2 tile[16 * 65];
-    __shared__ __attribute__((aligned(16))) float2 xwin[2][XB];
+    __shared__ __attribute__((aligned(16))) float2 srw[2][64];  // [block parity][7 k + q]: the shared sums of a block's eight outputs
     __shared__ float4 ring[2][4 * 64];   // [block parity][output pair][channel lane]
+    __shared__ float4 ring1[2][2 * 64];  // the same for halfband 1's four outputs of a block
     __shared__ float2 htile[8 * 65];
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0, 1: first-stage outputs 0..3 / 4..7; 2: the halfbands
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0, 1: first-stage outputs 0..3 / 4..7; 2: halfband 1; 3: halfbands 2 and 3
     const int cbase = blockIdx.y * 64;
     const bool live = cbase + lane < P.n_chan;
     const int c = live ? cbase + lane : P.n_chan - 1;
-    const int S = SFIX ? SFIX : P.S;
+    const int S = P.S;
     const long long o0 = (long long)blockIdx.x * P.L;
     if (o0 >= P.n_out) return;  // workgroup-uniform
     const long long o1 = o0 + P.L < P.n_out ? o0 + P.L : P.n_out;
@@ -115,7 +118,7 @@ static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__re
     const long long o_end = last_chunk ? o1 + 1 : o1;  // the last chunk runs one more block (o == n_out) whose first-stage outputs only feed the history
     const long long ob0 = o_start >= 0 ? o_start : 0;
     const int nb = (int)(o_end - o_start);
-    const int n_iter = nb + 1;            // the halfbands run one block behind
+    const int n_iter = nb + 2;            // halfband 1 runs one block behind the producers, halfbands 2 and 3 two
     const int it0 = (int)(ob0 - o_start);  // the first iteration that produces (chunk 0's warm-up blocks come from the history)
     const float2 *yh = y0_hist + (long long)c * P.y0_pitch;
 
@@ -132,54 +135,53 @@ static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__re
 
     if (role < 2) {
         // ------------------------------ producers ------------------------------
-        // ck[k][t] = h[d_t] step[d_t] rot^k, d_t = 0 2 4 5 6 8 10: the rotation from output to output inside a wave's four is
-        // folded into the constants (28 register pairs; the producers have them to spare -- the halfbands set the kernel's budget)
+        // The hb11's seven taps pair up around the centre: h[5+e] (step[5+e] x[5+e] + step[5-e] x[5-e]) =
+        //   step[5] h[5+e] (cos(e t) (x[5+e] + x[5-e]) + j sin(e t) (x[5+e] - x[5-e])),  t = 2 pi inc, e = 1 3 5, x[d] = x[S j - 10 + d],
+        // so  y0[j] = pa5(j) (h5 x5 + sum_e hc_e s_e + hs_e r_e),  s_e = x[5+e] + x[5-e],  r_e = j (x[5+e] - x[5-e]),
+        //     pa5(j) = amp e^{j 2 pi (phase0 + (S j - 4) inc)}:
+        // the sums s_e and rotated differences r_e do not depend on the channel -- wave 0 forms them once per output and block
+        // (56 lanes: 8 outputs x {h5 x5, s1, r1, s3, r3, s5, r5}, two raw samples each, straight from global memory) and parks them
+        // in LDS; a producer then spends six packed FMAs with REAL per-channel coefficients per output instead of fourteen
+        // (the complex products of the tap-by-tap form), and holds 6 coefficient registers instead of 56.
         const float amp = mix ? P.a_inf * P.gain0 : P.gain0;
-        v2f_t ck[4][7];
-        v2f_t rot8 = {1.f, 0.f};
-        {
-            constexpr int dt[7] = {0, 2, 4, 5, 6, 8, 10};
+        v2f_t hcs[3];  // (hc_e, hs_e) = h[5+e] (cos, sin)(e t)
+        v2f_t rot = {1.f, 0.f}, rot8 = {1.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float2 rk = mix ? cis_cycles((double)(k * S) * inc) : make_float2(1.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < 7; q++) {
-                    const float hd = dt[q] == 0 ? hb_tap<11>(0) : dt[q] == 2 ? hb_tap<11>(2) : dt[q] == 4 ? hb_tap<11>(4) : dt[q] == 5 ? hb_tap<11>(5)
-                                   : dt[q] == 6 ? hb_tap<11>(6) : dt[q] == 8 ? hb_tap<11>(8) : hb_tap<11>(10);
-                    float2 cd = make_float2(hd, 0.f);
-                    if (mix && dt[q] != 0) cd = cscale(oc->step[dt[q]], hd);
-                    const float2 v = cmul(rk, cd);
-                    ck[k][q] = v2f_t{v.x, v.y};
-                }
-            }
-            if (mix) {
-                const float2 r8 = cis_cycles((double)(8 * S) * inc);
-                rot8 = v2f_t{r8.x, r8.y};
-            }
+        for (int q = 0; q < 3; q++) {
+            const float hq = q == 0 ? hb_tap<11>(6) : q == 1 ? hb_tap<11>(8) : hb_tap<11>(10);
+            const float2 e = mix ? oc->step[2 * q + 1] : make_float2(1.f, 0.f);
+            hcs[q] = v2f_t{hq * e.x, hq * e.y};
+        }
+        if (mix) {
+            const float2 r1 = cis_cycles((double)S * inc), r8 = cis_cycles((double)(8 * S) * inc);
+            rot = v2f_t{r1.x, r1.y};
+            rot8 = v2f_t{r8.x, r8.y};
         }
         const int k0 = 4 * role;  // this wave's outputs of a block: k0 .. k0 + 3
-        const int nl = 7 * S + 11 > 64 ? 2 : 1;
-        // ONE load per 64 samples whatever the block (samples before the call's start come from the previous call's tail;
-        // lanes before that tail or past the end load a valid address and are never read): with a fixed number of loads per
-        // fetch the compiler can count, and the wait before a park leaves the younger fetch in flight
+        // feeder lane l < 56: output k = l / 7 of the block, quantity q = l % 7 (0: h5 x5; 1 3 5: s_e; 2 4 6: r_e; e = 1 1 3 3 5 5).
+        // Always two loads per lane (samples before the call's start come from the previous call's tail; lanes before that tail
+        // or past the end load a valid address and are never used): with a fixed number of loads per fetch the compiler can count,
+        // and the wait before a park leaves the younger fetch in flight
+        const int fl = lane < 56 ? lane : 55, fk = fl / 7, fq = fl - 7 * fk, fe = fq == 0 ? 0 : 2 * ((fq - 1) >> 1) + 1;
         auto fetch = [&](long long o, float2 (&r)[2]) {
-            const long long b = (long long)S * (8 * o - 7) - 10;
+            const long long b = (long long)S * (8 * o - 7 + fk) - 5;  // the centre tap's sample
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                if (q < nl) {
-                    long long i = b + lane + 64 * q;
-                    i = i < n_in ? i : n_in - 1;
-                    const float2 *p = i >= 0 ? in + i : x_hist + (i >= -16 ? 16 + i : 0);
-                    r[q] = *p;
-                }
+                long long i = b + (q == 0 ? fe : -fe);
+                i = i < n_in ? i : n_in - 1;
+                const float2 *p = i >= 0 ? in + i : x_hist + (i >= -16 ? 16 + i : 0);
+                r[q] = *p;
             }
         };
-        // two windows in flight, in two register sets that swap roles from block to block (the loop is unrolled by two: a
+        // two blocks in flight, in two register sets that swap roles from block to block (the loop is unrolled by two: a
         // register move would have to wait for the load it moves)
         float2 xn[2], xn2[2];
         auto park = [&](long long o, const float2 (&r)[2]) {
-            xwin[o & 1][lane] = r[0];
-            if (nl > 1) xwin[o & 1][lane + 64] = r[1];
+            const float h5 = hb_tap<11>(5);
+            const float2 sum = cadd(r[0], r[1]), dif = csub(r[0], r[1]);
+            float2 v = (fq & 1) ? sum : make_float2(-dif.y, dif.x);
+            if (fq == 0) v = cscale(r[0], h5);
+            srw[o & 1][lane] = v;
         };
         if (role == 0) {
             fetch(ob0, xn);
@@ -189,57 +191,38 @@ static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__re
         }
         __syncthreads();
         v2f_t pa_blk = {amp, 0.f};
-        // one block; FEEDER (wave 0) also parks block o + 1's window (the buffer the block before this one read) and starts
-        // the fetch of block o + 3 into the registers that held it.  No condition around the fetch, and one copy of the loop per
-        // role: only then does the compiler know that exactly one younger load is in flight when it waits for the parked one.
+        // one block; FEEDER (wave 0) also parks block o + 1's sums (the buffer the block before this one read) and starts
+        // the fetch of block o + 3 into the registers that held them.  No condition around the fetch, and one copy of the loop per
+        // role: only then does the compiler know that exactly one younger fetch is in flight when it waits for the parked one.
         auto produce = [&](auto feeder, long long o, float2 (&xq)[2]) {
-            const float2 *xw = xwin[o & 1] + S * k0;  // this wave's first window
             const long long j0 = 8 * o - 7;
             if (((o - o_start) & 7) == 0 || o == 0) {
                 // exact phase every eighth block (each producer for its own first output), a constant rotation in between
                 if (mix) {
-                    const float2 e = cscale(cis_cycles(phase0 + (double)((long long)S * (j0 + k0) - 9) * inc), amp);
+                    const float2 e = cscale(cis_cycles(phase0 + (double)((long long)S * (j0 + k0) - 4) * inc), amp);
                     pa_blk = v2f_t{e.x, e.y};
                 }
             } else {
                 pa_blk = cmul_pk(rot8, pa_blk);
             }
-            // the four windows x[S k + d]: at S = 4 they are 23 consecutive samples (twelve 16-byte broadcast reads)
-            v2f_t xs[4][7];
-            if (SFIX == 4) {
-                float4 x4[12];
+            // this wave's 4 x 7 shared quantities: 224 consecutive bytes, the same address in every lane
+            const float4 *sp = reinterpret_cast<const float4 *>(srw[o & 1] + 7 * k0);
+            float4 s4[14];
 #pragma unroll
-                for (int m = 0; m < 12; m++) x4[m] = reinterpret_cast<const float4 *>(xw)[m];
-                constexpr int dt[7] = {0, 2, 4, 5, 6, 8, 10};
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        const int i = 4 * k + dt[q];
-                        xs[k][q] = (i & 1) ? v2f_t{x4[i / 2].z, x4[i / 2].w} : v2f_t{x4[i / 2].x, x4[i / 2].y};
-                    }
-            } else {
-                constexpr int dt[7] = {0, 2, 4, 5, 6, 8, 10};
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        const float2 v = xw[S * k + dt[q]];
-                        xs[k][q] = v2f_t{v.x, v.y};
-                    }
-            }
-            // two chains per output (taps 0 4 6 10 | 2 5 8), four outputs: eight independent chains for the issue slots
+            for (int m = 0; m < 14; m++) s4[m] = sp[m];
             v2f_t y[4];
+            v2f_t pa = pa_blk;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                v2f_t ea = cmul_pk(ck[k][0], xs[k][0]);
-                v2f_t eb = cmul_pk(ck[k][1], xs[k][1]);
-                ea = cmac_pk(ea, ck[k][2], xs[k][2]);
-                eb = cmac_pk(eb, ck[k][3], xs[k][3]);
-                ea = cmac_pk(ea, ck[k][4], xs[k][4]);
-                eb = cmac_pk(eb, ck[k][5], xs[k][5]);
-                ea = cmac_pk(ea, ck[k][6], xs[k][6]);
-                y[k] = cmul_pk(pa_blk, ea + eb);
+                auto sv = [&](int q) { const int i = 7 * k + q; return (i & 1) ? v2f_t{s4[i / 2].z, s4[i / 2].w} : v2f_t{s4[i / 2].x, s4[i / 2].y}; };
+                v2f_t acc = sv(0);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    acc = fma_lo_pk(acc, hcs[q], sv(1 + 2 * q));
+                    acc = fma_hi_pk(acc, hcs[q], sv(2 + 2 * q));
+                }
+                y[k] = cmul_pk(pa, acc);
+                if (k < 3) pa = cmul_pk(rot, pa);
             }
             float4 *rg = ring[o & 1] + (k0 / 2) * 64 + lane;
             rg[0] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
@@ -258,7 +241,8 @@ static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__re
                 produce(feeder, o_start + it + 1, xn2);
             }
             if (it < nb) produce(feeder, o_start + it, xn);
-            __syncthreads();  // (the halfbands' last block)
+            __syncthreads();  // (the halfbands' last two blocks)
+            __syncthreads();
         };
         if (role == 0) run(std::true_type{});
         else run(std::false_type{});
@@ -279,116 +263,134 @@ static __global__ __launch_bounds__(192) void k_mix_dec_fused(const float2 *__re
         return;
     }
 
-    // ------------------------------ consumer: the halfbands, one block behind ------------------------------
-    float2 a1[N1], a2[N2], a3[N3];
+    // ------------------------------ the halfbands: wave 2 stage 1 (one block behind), wave 3 stages 2 and 3 (two behind) ------------------------------
+    auto bc = [](float h) { return make_float2(h, h); };
+    if (role == 2) {
+        float2 a1[N1];
 #pragma unroll
-    for (int i = 0; i < N1; i++) a1[i] = make_float2(0.f, 0.f);
+        for (int i = 0; i < N1; i++) a1[i] = make_float2(0.f, 0.f);
+        __syncthreads();  // (the producers' prologue barrier)
+        for (int it = 0; it < n_iter; it++) {
+            const long long o = o_start + it - 1;  // the block this wave works on in this iteration
+            if (it >= 1 && it <= nb) {
+                const long long j0 = 8 * o - 7;
+                float2 y0[8];
+                if (o <= 0) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) y0[k] = yh[j0 + k];  // chunk 0's warm-up: the previous call's tail (block 0: only output 0 is new)
+                    if (o < 0) {
+                        y0[7] = yh[j0 + 7];
+                    } else {
+                        const float4 v = ring[0][3 * 64 + lane];
+                        y0[7] = make_float2(v.z, v.w);
+                    }
+                } else {
+                    const float4 *rg = ring[o & 1] + lane;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float4 v = rg[k * 64];
+                        y0[2 * k] = make_float2(v.x, v.y);
+                        y0[2 * k + 1] = make_float2(v.z, v.w);
+                    }
+                }
+                const bool keep = last_chunk && o >= 0 && j0 + 7 >= len0 - HY;
+                if (keep) {  // eight outputs x 64 channels -> 64-byte row segments of the history staging rows
+#pragma unroll
+                    for (int k = 0; k < 8; k++) htile[k * 65 + lane] = y0[k];
+                    wave_sync();
+#pragma unroll 1
+                    for (int i8 = 0; i8 < 8; i8++) {
+                        const int idx = i8 * 64 + lane;
+                        const int ch = idx >> 3, k = idx & 7;
+                        const long long j = j0 + k;
+                        if (cbase + ch < P.n_chan && j >= len0 - HY && j < len0)
+                            y0_stage[(long long)(cbase + ch) * HY + (j - (len0 - HY))] = htile[k * 65 + ch];
+                    }
+                    wave_sync();
+                }
+                if (o != P.n_out) {
+                    float2 y1[4];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (k & 1) {  // j even: the even taps of stage 1; y1[4 o - 3 + b] is complete
+                            const int b = (k - 1) / 2;
+#pragma unroll
+                            for (int t = 0; t < (T1 + 1) / 2; t++) {
+                                const float2 v = y0[k] * bc(hb_tap<T1>(T1 - 1 - 2 * t));
+                                a1[b + t] = t == (T1 + 1) / 2 - 1 ? v : a1[b + t] + v;
+                            }
+                            y1[b] = a1[b];
+                        } else {
+                            a1[(k + PC1 - 1) / 2] = a1[(k + PC1 - 1) / 2] + y0[k] * bc(hb_tap<T1>(PC1));
+                        }
+                    }
+                    float4 *wr = ring1[o & 1] + lane;
+                    wr[0] = make_float4(y1[0].x, y1[0].y, y1[1].x, y1[1].y);
+                    wr[64] = make_float4(y1[2].x, y1[2].y, y1[3].x, y1[3].y);
+#pragma unroll
+                    for (int i = 0; i + 4 < N1; i++) a1[i] = a1[i + 4];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    float2 a2[N2], a3[N3];
 #pragma unroll
     for (int i = 0; i < N2; i++) a2[i] = make_float2(0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < N3; i++) a3[i] = make_float2(0.f, 0.f);
     float2 y3 = make_float2(0.f, 0.f);
-    auto feed = [&](int k, float2 y0) {
-        auto bc = [](float h) { return make_float2(h, h); };
-        if (k & 1) {
-            const int b = (k - 1) / 2;
-#pragma unroll
-            for (int t = 0; t < (T1 + 1) / 2; t++) {
-                const float2 v = y0 * bc(hb_tap<T1>(T1 - 1 - 2 * t));
-                a1[b + t] = t == (T1 + 1) / 2 - 1 ? v : a1[b + t] + v;
-            }
-            const float2 y1 = a1[b];
-            if (b & 1) {
-                const int b2 = (b - 1) / 2;
-#pragma unroll
-                for (int t = 0; t < (T2 + 1) / 2; t++) {
-                    const float2 v = y1 * bc(hb_tap<T2>(T2 - 1 - 2 * t));
-                    a2[b2 + t] = t == (T2 + 1) / 2 - 1 ? v : a2[b2 + t] + v;
-                }
-                const float2 y2 = a2[b2];
-                if (b2 & 1) {
-#pragma unroll
-                    for (int t = 0; t < (T3 + 1) / 2; t++) {
-                        const float2 v = y2 * bc(hb_tap<T3>(T3 - 1 - 2 * t));
-                        a3[t] = t == (T3 + 1) / 2 - 1 ? v : a3[t] + v;
-                    }
-                    y3 = a3[0];
-                } else {
-                    a3[(PC3 - 1) / 2] = a3[(PC3 - 1) / 2] + y2 * bc(hb_tap<T3>(PC3));
-                }
-            } else {
-                a2[(b + PC2 - 1) / 2] = a2[(b + PC2 - 1) / 2] + y1 * bc(hb_tap<T2>(PC2));
-            }
-        } else {
-            a1[(k + PC1 - 1) / 2] = a1[(k + PC1 - 1) / 2] + y0 * bc(hb_tap<T1>(PC1));
-        }
-    };
     __syncthreads();  // (the producers' prologue barrier)
     for (int it = 0; it < n_iter; it++) {
-        const long long o = o_start + it - 1;  // the block consumed in this iteration
-        if (it >= 1 && it <= nb) {
-            const long long j0 = 8 * o - 7;
-            float2 y0[8];
-            if (o <= 0) {
+        const long long o = o_start + it - 2;
+        if (it >= 2 && o != P.n_out) {  // (the history-only block has no outputs)
+            const float4 *rd = ring1[o & 1] + lane;
+            const float4 v01 = rd[0], v23 = rd[64];
+            const float2 y1[4] = {make_float2(v01.x, v01.y), make_float2(v01.z, v01.w), make_float2(v23.x, v23.y), make_float2(v23.z, v23.w)};
 #pragma unroll
-                for (int k = 0; k < 7; k++) y0[k] = yh[j0 + k];  // chunk 0's warm-up: the previous call's tail (block 0: only output 0 is new)
-                if (o < 0) {
-                    y0[7] = yh[j0 + 7];
-                } else {
-                    const float4 v = ring[0][3 * 64 + lane];
-                    y0[7] = make_float2(v.z, v.w);
-                }
-            } else {
-                const float4 *rg = ring[o & 1] + lane;
+            for (int b = 0; b < 4; b++) {
+                if (b & 1) {  // m even
+                    const int b2 = (b - 1) / 2;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float4 v = rg[k * 64];
-                    y0[2 * k] = make_float2(v.x, v.y);
-                    y0[2 * k + 1] = make_float2(v.z, v.w);
-                }
-            }
-            const bool keep = last_chunk && o >= 0 && j0 + 7 >= len0 - HY;
-            if (keep) {  // eight outputs x 64 channels -> 64-byte row segments of the history staging rows
-#pragma unroll
-                for (int k = 0; k < 8; k++) htile[k * 65 + lane] = y0[k];
-                wave_sync();
-#pragma unroll 1
-                for (int i8 = 0; i8 < 8; i8++) {
-                    const int idx = i8 * 64 + lane;
-                    const int ch = idx >> 3, k = idx & 7;
-                    const long long j = j0 + k;
-                    if (cbase + ch < P.n_chan && j >= len0 - HY && j < len0)
-                        y0_stage[(long long)(cbase + ch) * HY + (j - (len0 - HY))] = htile[k * 65 + ch];
-                }
-                wave_sync();
-            }
-            if (o != P.n_out) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    feed(k, y0[k]);
-                }
-                if (o >= o0 && o < o1) {
-                    const int jt = (int)(o - o0) & 15;
-                    tile[jt * 65 + lane] = cscale(y3, P.gain);
-                    if (jt == 15 || o == o1 - 1) {
-                        const long long ob = o - jt;
-                        wave_sync();
-#pragma unroll 1  // (unrolled, the sixteen row pointers are carried, and stepped, through every block)
-                        for (int i16 = 0; i16 < 16; i16++) {
-                            const int idx = i16 * 64 + lane;
-                            const int ch = idx >> 4, t = idx & 15;
-                            if (cbase + ch < P.n_chan && t <= jt) out[(long long)(cbase + ch) * P.out_pitch + ob + t] = tile[t * 65 + ch];
-                        }
-                        wave_sync();
+                    for (int t = 0; t < (T2 + 1) / 2; t++) {
+                        const float2 v = y1[b] * bc(hb_tap<T2>(T2 - 1 - 2 * t));
+                        a2[b2 + t] = t == (T2 + 1) / 2 - 1 ? v : a2[b2 + t] + v;
                     }
+                    const float2 y2 = a2[b2];
+                    if (b2 & 1) {  // q even: y3[o] is complete
+#pragma unroll
+                        for (int t = 0; t < (T3 + 1) / 2; t++) {
+                            const float2 v = y2 * bc(hb_tap<T3>(T3 - 1 - 2 * t));
+                            a3[t] = t == (T3 + 1) / 2 - 1 ? v : a3[t] + v;
+                        }
+                        y3 = a3[0];
+                    } else {
+                        a3[(PC3 - 1) / 2] = a3[(PC3 - 1) / 2] + y2 * bc(hb_tap<T3>(PC3));
+                    }
+                } else {
+                    a2[(b + PC2 - 1) / 2] = a2[(b + PC2 - 1) / 2] + y1[b] * bc(hb_tap<T2>(PC2));
                 }
-#pragma unroll
-                for (int i = 0; i + 4 < N1; i++) a1[i] = a1[i + 4];
-#pragma unroll
-                for (int i = 0; i + 2 < N2; i++) a2[i] = a2[i + 2];
-#pragma unroll
-                for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
             }
+            if (o >= o0 && o < o1) {
+                const int jt = (int)(o - o0) & 15;
+                tile[jt * 65 + lane] = cscale(y3, P.gain);
+                if (jt == 15 || o == o1 - 1) {
+                    const long long ob = o - jt;
+                    wave_sync();
+#pragma unroll 1  // (unrolled, the sixteen row pointers are carried, and stepped, through every block)
+                    for (int i16 = 0; i16 < 16; i16++) {
+                        const int idx = i16 * 64 + lane;
+                        const int ch = idx >> 4, t = idx & 15;
+                        if (cbase + ch < P.n_chan && t <= jt) out[(long long)(cbase + ch) * P.out_pitch + ob + t] = tile[t * 65 + ch];
+                    }
+                    wave_sync();
+                }
+            }
+#pragma unroll
+            for (int i = 0; i + 2 < N2; i++) a2[i] = a2[i + 2];
+#pragma unroll
+            for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
         }
         __syncthreads();
     }

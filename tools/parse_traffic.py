@@ -43,7 +43,8 @@ def main(fetch_dir, write_dir, out):
         cal[lanes] = {"fetch_KiB": f, "write_KiB": w, "read_scale": gib / (f * 1024.0), "write_scale": gib / (w * 1024.0)}
     res = {"calibration": cal, "kernels": {}}
     # loads: k_spectrum and k_wfm_fir/k_cascade use 8-byte lanes, k_mix_dec1 / k_mix_hb11_lean / k_mix_hb11_bank 16-byte lanes; stores: spectrum 16-byte, rest 8-byte
-    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_mix_hb11_lean": (16, 8), "k_mix_hb11_bank": (16, 8), "k_cascade": (8, 8), "k_wfm_fir": (8, 8)}
+    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_mix_hb11_lean": (16, 8), "k_mix_hb11_bank": (16, 8), "k_cascade": (8, 8), "k_wfm_fir": (8, 8),
+             "k_mix_dec_fused": (8, 8), "k_fastfir_t128": (8, 8), "k_demod_copy": (8, 8)}
     for name, (lr, lw) in lanes.items():
         f, w = first(fe, name), first(wr, name)
         if f is None:

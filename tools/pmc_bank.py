@@ -9,6 +9,9 @@ import numpy as np  # noqa: E402
 import pebblesdr_amd as P  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "2"
+if os.environ.get("PMC_CALIBRATE"):  # the traffic passes: two copies of known size first (tools/parse_traffic.py scales FETCH_SIZE by them)
+    P.binding.probe_copy_gbps(16, 1 << 30, 2)
+    P.binding.probe_copy_gbps(8, 1 << 30, 2)
 fs, C, modes, k = (2048000, 256, [P.DM_USB], 8) if which == "2" else (100000000, 512, [P.DM_AM, P.DM_USB], 1)
 rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=k)
 for c in range(C):
