@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- IQ Msamples/s through the full receive chain on MI355X (BASELINE.json metric).
 
 Headline workload (BASELINE.json configs[1]): synthetic 20 Msps HackRF-shape IQ, one tuned channel per GPU, mixer ->

@@ -367,7 +367,7 @@ private:
     // No events of its own: the chain stream waits for the call's start event, the call's end event is recorded on the chain
     // stream once it has also seen the transform's end event, and whatever next touches the main stream (the next call, a
     // synchronise) first waits for that end event.  Every event record costs the stream ~5 us, so none is spent on the fork/join.
-    hipEvent_t chain_end_ = nullptr;  // the end event of a two-stream call the main stream has not waited for yet
+    hipEvent_t chain_end_ = nullptr;  // set when a two-stream call failed half-way: what was queued on the chain stream, for the main stream to wait on
     std::vector<ChanCtl> ctl_;
     bool am_list_dirty_ = true, sm_dirty_ = true;
     long long pll_cap_ = 0;

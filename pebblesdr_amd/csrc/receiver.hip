@@ -451,10 +451,13 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
         if (int rc = run_save_tails(cs, jobs, C)) return rc;
     }
-    if (side) {  // join: the call has ended once both pipelines have; the main stream catches up with it at its next use
+    if (side) {
+        // join: the call has ended once both pipelines have, and it ends on the chain's stream.  That stream is the main stream
+        // of the next call (the two swap roles): its first kernel then follows this call's last in queue order, where a wait
+        // on an event from the other queue cost ~25 us of idle GPU per call
         PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
         PG_HIP(hipEventRecord(ev[6], cs));
-        chain_end_ = ev[6];
+        std::swap(stream_, chain_stream_);
     } else {
         PG_HIP(hipEventRecord(ev[6], stream_));
     }

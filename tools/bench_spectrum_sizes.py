@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the display transform alone for 2048 / 4096 / 8192 bins on the bench batch (16384 frames of 2048 samples)."""
 import json
 import os

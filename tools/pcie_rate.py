@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """DEVELOPER-ONLY: what the bench workload runs at when the host hands over pageable host buffers (PCIe both ways) -- the
 figure DESIGN.md section 5 quotes next to the HBM-resident rate.  Never the bench value."""
 import sys, time
