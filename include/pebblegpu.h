@@ -143,8 +143,13 @@ int pebblegpu_set_mixer_freq(pebblegpu_receiver *rx, uint32_t channel, double fr
  * (lo, hi, offset 0, demod rate) and, for AM channels, Demod_AM::setBandwidth(hi - lo). */
 int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_hz, double hi_hz);
 /* Receiver::demodModeChanged -> Demod::setDemodMode (receiver.cpp:640-655).  Narrow banks accept AM, SAM, FMN and
- * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM (mono).  FMS (stereo + RDS) is a
- * later row. */
+ * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM (mono) and FMS.
+ * FMS returns what Demod_WFM::processDataStereo (demod_wfm.cpp:255-365) delivers once its pilot PLL has dropped out, which it
+ * does within the first blocks on any input (the phase detector of processPilotPll, :390-430 / :792-821, is discontinuous at
+ * the loop's operating point; pinned on the oracle's line-by-line restatement, tests/test_oracle_pins.py): the discriminator
+ * output WITHOUT processDataMono's 75 kHz pre-filter, low-passed, de-emphasised and notched, the same signal in both
+ * channels.  Not reproduced: the blocks before the drop-out (at most the first three of a stream, where the reference
+ * demultiplexes with an unsettled pilot phase) and the RDS bit decoder (GUI text). */
 int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
 /* AGC::setAgcMode(mode, threshold) (application/agc.cpp:53-82; Receiver::agcModeChanged/agcThresholdChanged).
  * agc_mode: the reference's AgcMode values.  With PEBBLEGPU_AGC_OFF the threshold is a manual gain slider in dB

@@ -786,6 +786,7 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 {
     C = channels;
     rate = demod_rate;
+    stereo.assign(C, 0);
     lp_on = rate >= 150000;  // demod_wfm.cpp:210
     const design::Biquad l = design::biquad_lowpass(75000, 1.0, rate);   // demod_wfm.cpp:164
     const double lpc[5] = {l.b0, l.b1, l.b2, l.a1, l.a2};
@@ -842,16 +843,31 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 void WfmCore::release()
 {
     a.release(); b.release(); c.release();
-    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_h, d_hlp, d_xtail[0], d_xtail[1]};
+    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_h, d_hlp, d_xtail[0], d_xtail[1], d_stereo};
+    d_stereo = nullptr;
     for (void *q : p) if (q) (void)hipFree(q);
     d_taps = nullptr;
     d_lp_state[0] = d_lp_state[1] = d_dn_state[0] = d_dn_state[1] = nullptr;
     d_h = nullptr; d_hlp = nullptr; d_xtail[0] = d_xtail[1] = nullptr;
 }
+int WfmCore::set_stereo(uint32_t ch, bool on)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (on && !fused) return fail(PEBBLEGPU_E_UNSUPPORTED, "dmFMS needs the single-kernel WFM path (this demodulator rate runs the sequential one)");
+    if (stereo[ch] != (unsigned char)on) stereo_dirty = true;
+    stereo[ch] = on;
+    return 0;
+}
 int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
 {
     if (n < kMaxTaps) return fail(PEBBLEGPU_E_SIZE, "WFM demod needs at least %d samples per call", kMaxTaps);
     last_n = n;
+    if (stereo_dirty) {  // (rare: a mode change)
+        if (!d_stereo) PG_HIP(hipMalloc((void **)&d_stereo, C));
+        PG_HIP(hipMemcpyAsync(d_stereo, stereo.data(), C, hipMemcpyHostToDevice, s));
+        PG_HIP(hipStreamSynchronize(s));
+        stereo_dirty = false;
+    }
     if (fused) {
         WfmFirParams wp;
         memset(&wp, 0, sizeof(wp));
@@ -860,7 +876,7 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         wp.gain = 0.25f;  // FMDEMOD_GAIN, demod_wfm.cpp:51
         const long long Lx = (long long)L4 + Llp;
         launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(256), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
-                   out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp);
+                   out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp, (const unsigned char *)d_stereo);
         PG_HIP(hipGetLastError());
         // next call's history = the last Lx samples of (old history | this call's input), into the other buffer; when the
         // call alone covers it the copy rides on the caller's tail-refresh launch (tail_jobs)

@@ -176,7 +176,8 @@ __host__ __device__ inline size_t wfm_fir_lds_bytes(int L4, int Llp)
 // xtail: [channel][L4 + Llp] input samples preceding in[0] (zeros before the first call)
 static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ xtail,
                                                         float2 *__restrict__ out, long long out_pitch, long long n, WfmFirParams wp,
-                                                        const float *__restrict__ h, const float *__restrict__ hlp)
+                                                        const float *__restrict__ h, const float *__restrict__ hlp,
+                                                        const unsigned char *__restrict__ no_prefilter /* [channel] or null: dmFMS, see WfmCore */)
 {
     HIP_DYNAMIC_SHARED(float2, dyn)
     const int L4 = wp.L4, Llp = wp.Llp;
@@ -189,7 +190,8 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
     const long long s = (long long)blockIdx.x * kWfmOutB;
     const float2 *x = in + (long long)c * in_pitch;
     const float2 *xt = xtail + (long long)c * Lx;
-    if (tid < kWfmLpMax) hl[tid] = tid < Llp ? hlp[tid] : 0.f;
+    const bool raw_iq = no_prefilter != nullptr && no_prefilter[c] != 0;  // processDataStereo has no 75 kHz low-pass: the identity response
+    if (tid < kWfmLpMax) hl[tid] = tid < Llp ? (raw_iq ? (tid == 0 ? 1.f : 0.f) : hlp[tid]) : 0.f;
     // ---- 1. input samples x0 .. x0+NX-1, x0 = s - L4 - Llp (history from the tail, nothing past n) ----
     const long long x0 = s - Lx;
     for (int j = tid; j < NX; j += 256) {

@@ -184,6 +184,12 @@ struct WfmCore {
     float2 *d_xtail[2] = {nullptr, nullptr};  // [C][L4 + Llp] input history, ping-pong
     const float2 *deferred_in = nullptr;      // set by run(): the history copy is left to tail_jobs()
     long long deferred_pitch = 0;
+    // dmFMS as the reference delivers it: processDataStereo's pilot PLL does not hold lock, so the block
+    // copies the discriminator output to both channels -- processDataMono without its 75 kHz pre-filter (demod_wfm.cpp:255-293)
+    std::vector<unsigned char> stereo;        // per channel: 1 = dmFMS
+    unsigned char *d_stereo = nullptr;        // device copy, uploaded by run() when dirty; null until a channel asks for it
+    bool stereo_dirty = false;
+    int set_stereo(uint32_t ch, bool on);
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);

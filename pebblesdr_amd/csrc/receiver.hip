@@ -125,9 +125,13 @@ int Receiver::set_mode(uint32_t ch, int mode)
 {
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     if (wfm) {
-        if (mode != PEBBLEGPU_DM_FMM) return fail(PEBBLEGPU_E_UNSUPPORTED, "a WFM bank demodulates FMM (mono) only");
+        if (mode != PEBBLEGPU_DM_FMM && mode != PEBBLEGPU_DM_FMS) return fail(PEBBLEGPU_E_UNSUPPORTED, "a WFM bank demodulates FMM and FMS only");
+        std::lock_guard<std::mutex> g(mu_);
+        if (int rc = wfmc_.set_stereo(ch, mode == PEBBLEGPU_DM_FMS)) return rc;
+        ctl_[ch].mode = mode;
+        return 0;
     } else if (mode == PEBBLEGPU_DM_FMM || mode == PEBBLEGPU_DM_FMS || mode < 0 || mode > PEBBLEGPU_DM_NONE) {
-        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d is not available in a narrow bank (WFM needs a wfm bank; stereo is a later row)", mode);
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d is not available in a narrow bank (FMM and FMS need a wfm bank)", mode);
     }
     std::lock_guard<std::mutex> g(mu_);
     if (ctl_[ch].mode != mode) am_list_dirty_ = true;

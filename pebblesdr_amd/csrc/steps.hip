@@ -329,9 +329,11 @@ int pebblegpu_demod_set_mode(pebblegpu_demod *d, int mode)
 {
     if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
     if (mode < 0 || mode > PEBBLEGPU_DM_NONE) return fail(PEBBLEGPU_E_INVALID, "bad mode %d", mode);
-    if (mode == PEBBLEGPU_DM_FMS) return fail(PEBBLEGPU_E_UNSUPPORTED, "WFM stereo / RDS is a later row (SURVEY 8f-4)");
     if ((mode == PEBBLEGPU_DM_AM || mode == PEBBLEGPU_DM_SAM || mode == PEBBLEGPU_DM_FMN) && d->am.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a narrow sample rate");
-    if (mode == PEBBLEGPU_DM_FMM && d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
+    if ((mode == PEBBLEGPU_DM_FMM || mode == PEBBLEGPU_DM_FMS) && d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
+    if (d->wfm.C) {  // dmFMS: what processDataStereo delivers once its pilot PLL has dropped out (see pebblegpu.h)
+        if (int rc = d->wfm.set_stereo(0, mode == PEBBLEGPU_DM_FMS)) return rc;
+    }
     d->mode = mode;
     return 0;
 }
@@ -345,7 +347,7 @@ int pebblegpu_demod_set_bandwidth(pebblegpu_demod *d, double bw)
 int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const double **out)
 {
     if (!d || !in || !out || n <= 0) return fail(PEBBLEGPU_E_INVALID, "bad argument");
-    if (d->mode != PEBBLEGPU_DM_AM && d->mode != PEBBLEGPU_DM_FMM && d->mode != PEBBLEGPU_DM_SAM && d->mode != PEBBLEGPU_DM_FMN) {
+    if (d->mode != PEBBLEGPU_DM_AM && d->mode != PEBBLEGPU_DM_FMM && d->mode != PEBBLEGPU_DM_FMS && d->mode != PEBBLEGPU_DM_SAM && d->mode != PEBBLEGPU_DM_FMN) {
         *out = in;  // demod.cpp:127-138
         return 0;
     }

@@ -223,6 +223,81 @@ def test_wfm_mono_demod_step(gpu_lib, oracle_mod, fsw):
         off += ln
 
 
+def _fm_stereo_mpx(fs, n_samples, pilot_phase=1.0):
+    """an FM-stereo multiplex (1 kHz left, 2.5 kHz right, 19 kHz pilot, 38 kHz DSB difference) on a 75 kHz-deviation carrier"""
+    t = np.arange(n_samples) / fs
+    left, right = 0.9 * np.sin(2 * np.pi * 1000 * t), 0.9 * np.sin(2 * np.pi * 2500 * t)
+    mpx = 0.45 * (left + right) + 0.1 * np.sin(2 * np.pi * 19000 * t + pilot_phase) + 0.45 * (left - right) * np.sin(2 * (2 * np.pi * 19000 * t + pilot_phase))
+    return 0.5 * np.exp(1j * 2 * np.pi * 75000 * np.cumsum(mpx) / fs)
+
+
+@pytest.mark.parametrize("fsw", [256000, 312500])
+def test_wfm_stereo_mode_is_the_reference_after_its_pilot_pll_drops_out(gpu_lib, oracle_mod, fsw):
+    """dmFMS (include/pebblegpu.h at pebblegpu_set_demod_mode): processDataStereo restated line by line in the oracle loses
+    pilot lock within its first three blocks and from then on delivers the discriminator output, without processDataMono's
+    75 kHz pre-filter, in both channels.  The device path is compared with exactly those blocks; switching FMS -> FMM -> FMS
+    on a running stream follows the oracle too, except for the switch transient: the reference carries the discriminator's last
+    sample and the mono pre-filter's state across the switch (one filtered, one not; the pre-filter asleep during the stereo
+    blocks), the device reads the true input history -- a one-sample difference that rings through the audio filters' ~700-tap
+    response, so the first block after a switch is compared behind it."""
+    import pebblesdr_amd as P
+    n, blocks = 2048, 16
+    x = _fm_stereo_mpx(fsw, n * blocks) + lcg_noise(n * blocks, 9, 1e-4)
+    ref = oracle_mod.DemodWFM(fsw)
+    d = P.Demod(64000, fsw, 4 * n)
+    d.setDemodMode(P.DM_FMS)
+    locks = []
+    for k in range(10):
+        fr = x[k * n:(k + 1) * n]
+        r, lk = ref.process_stereo(fr)
+        g = d.processBlock(fr)
+        locks.append(lk)
+        assert np.array_equal(g.real, g.imag)  # one signal in both channels
+        if k >= 3:
+            assert not lk and rel_rms(g, r) <= TOL
+    assert not any(locks[3:])
+    d.setDemodMode(P.DM_FMM)
+    for k in range(10, 13):
+        fr = x[k * n:(k + 1) * n]
+        r, g = ref.process(fr), d.processBlock(fr)
+        lo = 1024 if k == 10 else 0
+        assert rel_rms(g[lo:], r[lo:]) <= TOL
+    d.setDemodMode(P.DM_FMS)
+    for k in range(13, 16):
+        fr = x[k * n:(k + 1) * n]
+        r, lk = ref.process_stereo(fr)
+        g = d.processBlock(fr)
+        lo = 1024 if k == 13 else 0
+        assert not lk and rel_rms(g[lo:], r[lo:]) <= TOL
+
+
+def test_wfm_stereo_mode_in_the_receiver(gpu_lib, oracle_mod):
+    """The same through the whole chain: a 2.5 Msps WFM receiver in dmFMS against the oracle's Receiver in the same mode, from
+    the super-frame in which the oracle's pilot PLL has dropped out."""
+    import pebblesdr_amd as P
+    fs, n = 2_500_000, 2048
+    rx = P.ReceiverBank(fs, 1, True, True, 0, max_superframes=2)
+    rx.set_mode(0, P.DM_FMS)
+    rx.set_mixer(0, 250e3)
+    sf = rx.superframe
+    K = 8
+    base = _fm_stereo_mpx(fs, K * sf)
+    x = base * np.exp(2j * np.pi * 250e3 * np.arange(K * sf) / fs) + lcg_noise(K * sf, 4, 1e-4)
+    ref = oracle_mod.Receiver(fs, n, 0)
+    ref.set_mode(oracle_mod.FMS)
+    ref.set_mixer(250e3)
+    ra = []
+    for f in range(K * sf // n):
+        a, _ = ref.process(x[f * n:(f + 1) * n], want_spectrum=False)
+        if len(a):
+            ra.append(a)
+    ga = [rx.process(x[k * sf:(k + 1) * sf])[0][0] for k in range(K)]
+    assert len(ra) == K
+    for k in range(4, K):
+        assert np.array_equal(ga[k].real, ga[k].imag)
+        assert rel_rms(ga[k], ra[k]) <= TOL
+
+
 @pytest.mark.parametrize("bins", [2048, 4096, 8192, 16384, 32768])
 def test_spectrum_step(gpu_lib, oracle_mod, bins):
     """fftSpectrum: window, pruned zero-pad FFT, unfold, previous-frame averaging, dB, clip."""
@@ -898,7 +973,7 @@ def test_error_paths(gpu_lib):
         rx.set_bandpass(0, 3000, 300)  # lo >= hi: "Filter Parameter error"
     assert e.value.code == -4
     with pytest.raises(P.PebbleGpuError) as e:
-        rx.set_mode(0, P.DM_FMS)  # stereo WFM / RDS: a later row
+        rx.set_mode(0, P.DM_FMS)  # FMM / FMS need a WFM bank
     assert e.value.code == -6
     buf = P.DeviceBuffer(8 * 1000)
     with pytest.raises(P.PebbleGpuError) as e:
