@@ -444,6 +444,41 @@ def test_config3_shared_input_usb_bank(gpu_lib, oracle_mod):
             assert rel_rms(g[i][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL
 
 
+def test_fused_decimator_with_a_ragged_last_channel_group(gpu_lib, oracle_mod):
+    """The one-kernel decimator (k_mix_dec_fused) with 80 channels: its second 64-channel workgroup column has 16 live lanes.
+    Three calls of one super-frame (the second and third start from the first-stage history the kernel itself left), one
+    channel without a mixer frequency (the oscillator bypass) and a retune between calls (that call takes the two-kernel
+    route inside the oscillator's amplitude transient, the next one comes back)."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 80
+    fcs = [-900e3 + 22.5e3 * c for c in range(C)]
+    fcs[5] = 0.0
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    for c, fc in enumerate(fcs):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fc); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    K = 5
+    x = tones(fs, K * sf, [(0.004, fcs[c] + 700.0 + 11.0 * c, 0.1 * c) for c in range(C)]) + lcg_noise(K * sf, 8, 1e-3)
+    check = (0, 5, 63, 64, 79)
+    refs = {}
+    for c in check:
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fcs[c]); r.set_filter(300, 3000)
+        refs[c] = r
+    names = []
+    for k in range(K):
+        if k == 2:  # retune channel 64 between calls (its tone stays inside the pass-band: 1404 -> 904 Hz)
+            fcs[64] += 500.0
+            rx.set_mixer(64, fcs[64]); refs[64].set_mixer(fcs[64])
+        g = rx.process(x[k * sf:(k + 1) * sf])[0]
+        names.append(rx.kernel_name(2))
+        for c in check:
+            want = np.concatenate([refs[c].process(x[k * sf + f * n:k * sf + (f + 1) * n], want_spectrum=False)[0] for f in range(sf // n)])
+            assert rel_rms(g[c], want) <= TOL, (k, c)
+    # the first call after a (re)tune runs inside an oscillator's amplitude transient: general kernels; otherwise the fused one
+    assert names[1] == "k_mix_dec_fused" and names[4] == "k_mix_dec_fused" and names[2] != "k_mix_dec_fused"
+
+
 def test_config4_cic3_chain_mixed_am_usb(gpu_lib, oracle_mod):
     """BASELINE config 4 at parity size: 100 Msps shared input, chain cic3x16,hb11x16,hb15,hb23,hb47 (D = 2048),
     AM on even / USB on odd channels, 4 channels, 2 super-frames.  Oracle frame N = 49152 as SURVEY.md 8(d) prescribes
