@@ -188,7 +188,7 @@ int pebblegpu_receiver_last_ms(const pebblegpu_receiver *rx, int which, float *m
 /* name(s) of the kernel(s) behind group `which` (1..5) as the last process call ran them ("" when the group is empty): the
  * bench labels its per-kernel roofline lines with these */
 const char *pebblegpu_receiver_kernel_name(const pebblegpu_receiver *rx, int which);
-/* which 0 and 1 are always available (three event records per call).  The per-kernel splits 2..5 need four more
+/* which 0 and 1 are always available (two event records per call, three with a display transform; 1 reads 0 without one).  The per-kernel splits 2..5 need four more
  * records, each a ~5 us bubble in the stream, so they are recorded only after set_profiling(rx, 1). */
 int pebblegpu_receiver_set_profiling(pebblegpu_receiver *rx, int per_kernel);
 /* the same, averaged over the last `last_k` process calls (the library keeps events for 64): lets a caller queue calls

@@ -150,6 +150,8 @@ void OscBank::release()
     }
     if (d_osc) (void)hipFree(d_osc);
     if (d_amp) (void)hipFree(d_amp);
+    if (d_adv) (void)hipFree(d_adv);
+    d_adv = nullptr;
     d_osc = nullptr;
     d_amp = nullptr;
 }
@@ -161,6 +163,7 @@ void OscBank::retune(uint32_t ch, double f)
     c.phase0 = 0;       // m_lastOsc = (1, 0)  (mixer.cpp:37-38)
     c.n0 = 0;
     c.dirty = true;
+    adv_stale = true;
 }
 int OscBank::upload(hipStream_t s)
 {
@@ -185,6 +188,7 @@ int OscBank::upload(hipStream_t s)
         PG_HIP(hipStreamSynchronize(s));
         c.dirty = false;
     }
+    if (device_advance && dev_dyn_valid && C > (uint32_t)kOscInline) return 0;  // the previous call's tail launch advanced them on the device
     // every call: phase and amplitude-transient position, 16 bytes per channel, from pinned ping-pong staging
     const int cur = h_idx;
     h_idx ^= 1;
@@ -207,6 +211,31 @@ int OscBank::upload(hipStream_t s)
     }
     PG_HIP(hipMemcpy2DAsync(d_osc, sizeof(ChanOsc), hd, sizeof(Dyn), sizeof(Dyn), C, hipMemcpyHostToDevice, s));
     PG_HIP(hipEventRecord(h_done[cur], s));
+    return 0;
+}
+int OscBank::advance_job(hipStream_t s, uint64_t n, OscAdvance *oa)
+{
+    memset(oa, 0, sizeof(*oa));
+    dev_dyn_valid = false;
+    if (!device_advance || C <= (uint32_t)kOscInline) return 0;
+    if (!d_adv) PG_HIP(hipMalloc((void **)&d_adv, sizeof(double) * C));
+    if (adv_stale || adv_n != n) {  // (rare: a retune or another call length)
+        std::vector<double> a(C);
+        for (uint32_t ch = 0; ch < C; ch++) {
+            long double p = (long double)n * (long double)ctl[ch].inc;
+            p -= floorl(p);
+            a[ch] = (double)p;
+        }
+        PG_HIP(hipMemcpyAsync(d_adv, a.data(), sizeof(double) * C, hipMemcpyHostToDevice, s));
+        PG_HIP(hipStreamSynchronize(s));
+        adv_n = n;
+        adv_stale = false;
+    }
+    oa->osc = d_osc;
+    oa->adv = d_adv;
+    oa->adv_n = (uint32_t)(n > 0xffffffffull ? 0xffffffffull : n);
+    oa->osc_count = C;
+    dev_dyn_valid = true;
     return 0;
 }
 bool OscBank::any_transient() const
@@ -547,20 +576,22 @@ void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
     if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
 }
 
-int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels)
+int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa)
 {
-    if (jobs.empty()) return 0;
+    const bool adv = oa != nullptr && oa->osc != nullptr;
+    if (jobs.empty() && !adv) return 0;
     if (jobs.size() > (size_t)kMaxTailJobs) return fail(PEBBLEGPU_E_INVALID, "too many history buffers");
     TailJobs tj;
     memset(&tj, 0, sizeof(tj));
     tj.count = (int)jobs.size();
+    if (adv) tj.oa = *oa;
     int maxh = 1;
     for (size_t i = 0; i < jobs.size(); i++) {
         tj.job[i] = jobs[i];
         if (jobs[i].hist > maxh) maxh = jobs[i].hist;
     }
     if (maxh > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "history of %d samples too deep for the tail refresh", maxh);
-    launch(k_save_tails, dim3(1, channels, (unsigned)jobs.size()), dim3(256), s, tj);
+    launch(k_save_tails, dim3(1, channels, (unsigned)(jobs.empty() ? 1 : jobs.size())), dim3(256), s, tj);
     PG_HIP(hipGetLastError());
     return 0;
 }

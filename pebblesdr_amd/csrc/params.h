@@ -86,8 +86,17 @@ struct TailJob {
     long long dst_pitch;
 };
 constexpr int kMaxTailJobs = 12;
+// The oscillators' per-call fields can ride on the same launch: osc[c].phase0 += adv[c] (mod 1), n0 += adv_n (saturating at
+// kAmpTab) for c < osc_count -- OscBank::advance restated on the device, so a bank too large for kernel-argument transport
+// needs no host-to-device copy per call (a DMA-engine copy in the stream cost ~20 us of idle GPU each call).
+struct OscAdvance {
+    ChanOsc *osc;        // nullptr: nothing to advance
+    const double *adv;   // [osc_count] frac(n * inc), computed on the host in long double for this call length
+    uint32_t adv_n, osc_count;
+};
 struct TailJobs {
     int count, pad_;
+    OscAdvance oa;
     TailJob job[kMaxTailJobs];
 };
 

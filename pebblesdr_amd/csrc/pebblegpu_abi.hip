@@ -233,6 +233,7 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
             return fail(PEBBLEGPU_E_INVALID, "per-kernel times need pebblegpu_receiver_set_profiling(rx, 1) before the calls");
         float one = 0;
         PG_HIP(hipEventSynchronize(ev[6]));
+        if (which == 1 && !t.has_mid[(t.calls - 1 - k) % pg::Timers::kRing]) continue;  // no display transform in that call: 0 ms
         PG_HIP(hipEventElapsedTime(&one, ev[a[which]], ev[b[which]]));
         sum += one;
     }

@@ -36,7 +36,7 @@ void fill_scan_section(ScanSection &s, int type, const double *c);
 int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
-int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels);
+int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa = nullptr);
 int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale = 0.f);
 int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
                   int stride, uint32_t channels);
@@ -60,6 +60,16 @@ struct OscBank {
     ChanOsc *d_osc = nullptr;
     float *d_amp = nullptr;
     float a_inf = 0;
+    // Banks too large for kernel-argument transport (C > kOscInline): with device_advance set by the owner, the per-call fields
+    // are advanced ON the device at the end of each call (k_save_tails, OscAdvance) instead of being copied up before the next;
+    // the owner passes advance_job(n) to its tail-refresh launch.  d_adv holds frac(n * inc) per channel for the current call
+    // length, rebuilt (long double, as advance() computes) when the length or a frequency changes.
+    bool device_advance = false;
+    bool dev_dyn_valid = false;    // the device blocks hold the per-call fields of the coming call
+    double *d_adv = nullptr;
+    uint64_t adv_n = 0;
+    bool adv_stale = true;
+    int advance_job(hipStream_t s, uint64_t n, OscAdvance *oa);  // fills *oa (osc == nullptr when the device is not advancing)
     int init(uint32_t channels, double sample_rate);
     void release();
     void retune(uint32_t ch, double f);           // Mixer::setFrequency, mixer.cpp:25-40
@@ -299,6 +309,7 @@ struct Timers {
     static constexpr int kRing = 64;
     hipEvent_t ev[kRing][8] = {};
     bool detailed[kRing] = {};   // per-kernel events (2..5) were recorded for that call
+    bool has_mid[kRing] = {};    // event 1 (behind the display transform) was recorded: calls without a spectrum skip it unless profiling
     uint64_t calls = 0;
     hipEvent_t *slot() { return ev[calls % kRing]; }
 };

@@ -47,6 +47,7 @@ int Receiver::create(const pebblegpu_config *cfg)
     for (auto &c : ctl_) c.mode = wfm ? PEBBLEGPU_DM_FMM : PEBBLEGPU_DM_AM;  // Demod ctor default dmAM, demod.cpp:56
     if (int rc = osc_.init(C, fs)) return rc;
     osc_.allow_inline = true;
+    osc_.device_advance = true;  // (banks of more than kOscInline channels: no per-call copy of the oscillators' phases)
     // "Restore gain lost in decimation" 10^(2*stages/20) only on the narrow branch (receiver.cpp:935-938 vs :854-901)
     const float gain = wfm ? 1.f : (float)std::pow(10.0, (double)(chain.dec_by2 * 2) / 20.0);
     if (int rc = dec_.init(C, chain, max_n, wfm ? 0 : (int)ff_taps - 1, gain)) return rc;
@@ -363,8 +364,11 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             if (int rc = run_signal_strength(stream_, d_spec, F * (long long)bins, (int)bins, F, d_sm_bins, d_smeter, smeter_pitch, C)) return rc;
         }
     }
-    PG_HIP(hipEventRecord(ev[1], stream_));
+    // (every record is a ~5 us bubble in the stream: a call with no display transform does without the one behind it)
+    const bool mid = with_spectrum || profile_detail || side;
+    if (mid) PG_HIP(hipEventRecord(ev[1], stream_));
     tm.detailed[(tm.calls - 1) % Timers::kRing] = profile_detail;
+    tm.has_mid[(tm.calls - 1) % Timers::kRing] = mid;
     if (!with_chain) {
         if (profile_detail) for (int i = 2; i <= 5; i++) PG_HIP(hipEventRecord(ev[i], stream_));
         PG_HIP(hipEventRecord(ev[6], stream_));
@@ -453,7 +457,9 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
-        if (int rc = run_save_tails(cs, jobs, C)) return rc;
+        OscAdvance oa;
+        if (int rc = osc_.advance_job(cs, n, &oa)) return rc;
+        if (int rc = run_save_tails(cs, jobs, C, &oa)) return rc;
     }
     if (side) {
         // join: the call has ended once both pipelines have, and it ends on the chain's stream.  That stream is the main stream
