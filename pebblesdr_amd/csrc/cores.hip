@@ -512,7 +512,9 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             const int R = 8;
             const long long j_first = (10 + first.stride - 1) / first.stride;
             const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
-            launch(raw ? k_mix_hb11_lean<true> : k_mix_hb11_lean<false>, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc,
+            auto lean = !raw ? k_mix_hb11_lean<-1> : rs.fmt == 0 ? k_mix_hb11_lean<0> : rs.fmt == 1 ? k_mix_hb11_lean<1> : rs.fmt == 2 ? k_mix_hb11_lean<2>
+                             : rs.fmt == 3 ? k_mix_hb11_lean<3> : k_mix_hb11_lean<4>;
+            launch(lean, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc,
                    osc.a_inf, bank_taps, first.gain, osc.inline_dyn, R, j_first, rs);
             front_name = "k_mix_hb11_lean";
             launch(raw ? k_mix_hb11_bank<false, false, true> : k_mix_hb11_bank<false, false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch,

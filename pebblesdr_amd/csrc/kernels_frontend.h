@@ -601,7 +601,7 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
 // with pa(j) = a_inf e^{j 2 pi (phase0 + (S j - 9) inc)}: seven complex MACs and one product per output instead of
 // thirteen products and seven MACs.
 // grid ceil(n_out / (4 R 64)), block 256 (four independent waves, R outputs per lane each).
-template <bool RAW /* raw device-format input (RawSrc) converted in the window loads */>
+template <int FMT /* >= 0: raw device-format input (RawSrc, that sample format) converted in the window loads; -1: float2 `in` */>
 static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *__restrict__ in, float2 *__restrict__ out, long long n_out,
                                                                   const ChanOsc *__restrict__ osc, float a_inf, FrontTaps hb, float out_gain,
                                                                   OscDynInline dyn, int R, long long j_first, RawSrc raw)
@@ -629,9 +629,14 @@ static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *_
         if (mix) ph = r == 0 ? cscale(cis_cycles(phase0 + (double)(i0 + 1) * inc), a_inf * out_gain) : cmul(rot, ph);
         if (j < j_first || j >= n_out) continue;
         float2 s0, s2, s4, s5, s6, s8, s10;
-        if (RAW) {
-            s0 = raw_load(raw, i0); s2 = raw_load(raw, i0 + 2); s4 = raw_load(raw, i0 + 4); s5 = raw_load(raw, i0 + 5);
-            s6 = raw_load(raw, i0 + 6); s8 = raw_load(raw, i0 + 8); s10 = raw_load(raw, i0 + 10);
+        if (FMT >= 0) {
+            // the window's 11 samples as three wide loads of four (one 2-byte load per tap had this kernel run twice as long
+            // as its float2 form beside the display transform)
+            float2 w[12];
+            raw_load4_even<FMT>(raw, i0, reinterpret_cast<float2 (&)[4]>(w[0]));
+            raw_load4_even<FMT>(raw, i0 + 4, reinterpret_cast<float2 (&)[4]>(w[4]));
+            raw_load4_even<FMT>(raw, i0 + 8, reinterpret_cast<float2 (&)[4]>(w[8]));
+            s0 = w[0]; s2 = w[2]; s4 = w[4]; s5 = w[5]; s6 = w[6]; s8 = w[8]; s10 = w[10];
         } else {
             const float4 *p = reinterpret_cast<const float4 *>(in + i0);
             const float4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], x5 = p[5];

@@ -159,6 +159,37 @@ __device__ __forceinline__ void raw_load4(const RawSrc &r, long long i, float2 (
     }
 }
 
+// the same for any EVEN sample index i (the first stage's windows start at S j - 10): the chunk is then only 4-byte (int8
+// formats) or 8-byte (int16) aligned, which the global-memory path takes in one wide load all the same
+template <int FMT>
+__device__ __forceinline__ void raw_load4_even(const RawSrc &r, long long i, float2 (&o)[4])
+{
+    float v[8];
+    if (FMT == 0 || FMT == 1) {
+        unsigned w[2];
+        __builtin_memcpy(w, reinterpret_cast<const unsigned char *>(r.base) + 2 * i, 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned word = w[k >> 2];
+            const int sh = 8 * (k & 3);
+            v[k] = FMT == 0 ? (float)((int)(word << (24 - sh)) >> 24) : (float)((word >> sh) & 0xFFu) - 128.0f;
+        }
+    } else if (FMT == 2 || FMT == 4) {
+        unsigned w[4];
+        __builtin_memcpy(w, reinterpret_cast<const unsigned char *>(r.base) + 4 * i, 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (float)((int)(w[k >> 1] << (16 - 16 * (k & 1))) >> 16);
+    } else {
+        const float4 a = reinterpret_cast<const float4 *>(r.base)[i >> 1], b = reinterpret_cast<const float4 *>(r.base)[(i >> 1) + 1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float a = v[2 * k] * r.scale, b = v[2 * k + 1] * r.scale;
+        o[k] = r.order == 0 ? make_float2(a, b) : r.order == 1 ? make_float2(b, a) : r.order == 2 ? make_float2(a, a) : make_float2(b, b);
+    }
+}
+
 // Per-channel squelch gate of a bank (receiver.cpp:959-965 per channel): open[c * stride + j] != 0 <=> channel c's super-frame j of
 // this call passes.  The kernels behind the band-pass take one super-frame j at a time and leave a closed channel alone
 // (no output, no state change).  open == nullptr: no gate.
