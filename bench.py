@@ -213,6 +213,19 @@ def run_bank(P, name, fs, C, modes, k, rank, world, device, barrier, args, dist)
     groups = [(names[2], ms[2], front_b), (names[3], ms[3], rest_b), (names[4], ms[4], 16 * C * n // D),
               ("AM demod: k_iir_scan + k_fir_dec" if n_am else "", ms[5], 16 * n_am * n // D)]
     ks, roof = kernel_lines(groups)
+    if roof is not None and (fs, C, k) == (2048000, 256, 8):
+        # configs[2] exactly as the committed PMC passes ran it (tools/pmc_bank.py 2): measured HBM bytes per launch
+        path = os.path.join(ROOT, "profiles", "r02_traffic_configs2.json")
+        try:
+            meas = json.load(open(path))["kernels"]
+            for kn, v in ks.items():
+                if kn in meas:
+                    v["hbm_bytes_measured"] = int(round(meas[kn]["hbm_bytes"]))
+            if roof["kernel"] in meas:
+                roof["traffic"] = int(round(meas[roof["kernel"]]["hbm_bytes"]))
+                roof["traffic_source"] = "profiles/r02_traffic_configs2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, not collected in this run)"
+        except Exception:
+            pass
     t_ms = elapsed / args.steps * 1e3
     comp = 8 * n + 8 * C * n // D
     actual = sum(v["algorithmic_bytes"] for v in ks.values())
