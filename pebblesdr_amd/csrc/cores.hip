@@ -638,13 +638,13 @@ int FastFirCore::run(hipStream_t s, const HistBuf &in, long long n, float2 *out,
     if (n % L != 0) return fail(PEBBLEGPU_E_SIZE, "FastFIR input %lld is not a multiple of its block %lld", n, L);
     const dim3 grid((unsigned)(n / L), C), block(256);
     const float2 *no_tail = nullptr;
-    if (fft_n == 2048) launch(k_fastfir_t128, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail);
+    if (fft_n == 2048) launch(k_fastfir_t128, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr);
     else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     else launch(k_fastfir<8192>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     PG_HIP(hipGetLastError());
     return 0;
 }
-int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, float2 *d_tail, long long n, float2 *out, long long out_pitch)
+int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, float2 *d_tail, long long n, float2 *out, long long out_pitch, float2 *d_tail_next)
 {
     const int overlap = (int)taps - 1;
     const long long L = block_len();
@@ -653,7 +653,13 @@ int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, fl
     if (n == 0) return 0;
     const dim3 grid((unsigned)(n / L), C), block(256);
     const float2 *tail = d_tail;
-    if (fft_n == 2048) launch(k_fastfir_t128, grid, dim3(128), s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail);
+    if (fft_n == 2048) {
+        launch(k_fastfir_t128, grid, dim3(128), s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
+        if (d_tail_next) {  // the kernel's last block has written the next call's overlap into the caller's other buffer
+            PG_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
     else launch(k_fastfir<8192>, grid, block, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, tail);
     PG_HIP(hipGetLastError());

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_fastfir(const float2 *__restrict__ in, 
 static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__restrict__ in, long long in_pitch,
                                                              float2 *__restrict__ out, long long out_pitch,
                                                              const float2 *__restrict__ H, const float2 *__restrict__ tw128,
-                                                             int overlap /* taps-1 */, const float2 *__restrict__ tail)
+                                                             int overlap /* taps-1 */, const float2 *__restrict__ tail,
+                                                             float2 *__restrict__ tail_out /* or null: [c][overlap] receives the call's last `overlap` input samples */)
 {
     constexpr int N = 2048, E = 16;
     __shared__ float2 lds[FftLds<N>::kSlots];
@@ -82,6 +83,16 @@ static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__res
     } else {
 #pragma unroll
         for (int m = 0; m < E; m++) v[m] = x[t + 128 * m];
+    }
+    if (tail_out != nullptr && b == (long long)gridDim.x - 1) {
+        // m_pFFTOverlapBuf for the next call (fastfir.cpp:312-316): the last block's window ends with them.  A different buffer
+        // from `tail`, which block 0 of this launch may still be reading
+        float2 *to = tail_out + (long long)c * overlap;
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const int i = t + 128 * m;
+            if (i >= L) to[i - L] = v[m];
+        }
     }
     __syncthreads();
     fft2048_t128(v, lds, tw_lds, t, [] { __syncthreads(); });

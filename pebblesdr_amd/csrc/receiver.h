@@ -137,7 +137,9 @@ struct FastFirCore {
     // in: buffer with taps-1 head-room; n multiple of block_len()
     int run(hipStream_t s, const HistBuf &in, long long n, float2 *out, long long out_pitch);
     // caller-owned rows without head-room; d_tail [C][taps-1] carries the overlap between calls and is refreshed here
-    int run_ext(hipStream_t s, const float2 *in, long long in_pitch, float2 *d_tail, long long n, float2 *out, long long out_pitch);
+    // d_tail_next (2048-point plan only): a second [C][taps-1] buffer that receives the next call's overlap straight from the
+    // kernel (the caller alternates the two) instead of a copy launched behind it
+    int run_ext(hipStream_t s, const float2 *in, long long in_pitch, float2 *d_tail, long long n, float2 *out, long long out_pitch, float2 *d_tail_next = nullptr);
 };
 
 // ---- Demod_AM ----

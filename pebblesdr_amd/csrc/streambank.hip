@@ -9,7 +9,7 @@ struct pebblegpu_streambank {
     hipStream_t stream = nullptr;
     pg::FastFirCore ff;
     pg::SpectrumCore sp;
-    float2 *d_tail = nullptr, *d_filt = nullptr;
+    float2 *d_tail = nullptr, *d_tail_alt = nullptr, *d_filt = nullptr;  // (the two overlap buffers swap after every band-pass call)
     float *d_spec = nullptr;
     uint64_t cap = 0, last_n = 0, last_frames = 0;
     hipEvent_t ev[4] = {};
@@ -28,7 +28,7 @@ int pebblegpu_streambank_destroy(pebblegpu_streambank *sb)
     }
     sb->ff.release();
     sb->sp.release();
-    void *p[] = {sb->d_tail, sb->d_filt, sb->d_spec};
+    void *p[] = {sb->d_tail, sb->d_tail_alt, sb->d_filt, sb->d_spec};
     for (void *q : p) if (q) (void)hipFree(q);
     for (hipEvent_t e : sb->ev) if (e) (void)hipEventDestroy(e);
     delete sb;
@@ -60,6 +60,8 @@ int pebblegpu_streambank_create(const pebblegpu_streambank_config *cfg, pebblegp
         const size_t ov = sb->cfg.fastfir_taps - 1;
         PG_HIP(hipMalloc((void **)&sb->d_tail, sizeof(float2) * ov * S));
         PG_HIP(hipMemset(sb->d_tail, 0, sizeof(float2) * ov * S));  // m_pFFTOverlapBuf starts at zero, fastfir.cpp:104-105
+        PG_HIP(hipMalloc((void **)&sb->d_tail_alt, sizeof(float2) * ov * S));
+        PG_HIP(hipMemset(sb->d_tail_alt, 0, sizeof(float2) * ov * S));
         PG_HIP(hipMalloc((void **)&sb->d_filt, sizeof(float2) * sb->cap * S));
         PG_HIP(hipMalloc((void **)&sb->d_spec, sizeof(float) * (size_t)sb->sp.bins * cfg->max_frames * S));
         for (hipEvent_t &e : sb->ev) PG_HIP(hipEventCreate(&e));
@@ -95,7 +97,9 @@ int pebblegpu_streambank_process(pebblegpu_streambank *sb, const void *d_iq, uin
     if (n == 0) return 0;
     PG_HIP(hipEventRecord(sb->ev[0], sb->stream));
     if (what & 1u) {
-        if (int rc = sb->ff.run_ext(sb->stream, in, (long long)n, sb->d_tail, (long long)n, sb->d_filt, (long long)n)) return rc;
+        float2 *next = sb->ff.fft_n == 2048 ? sb->d_tail_alt : nullptr;
+        if (int rc = sb->ff.run_ext(sb->stream, in, (long long)n, sb->d_tail, (long long)n, sb->d_filt, (long long)n, next)) return rc;
+        if (next) std::swap(sb->d_tail, sb->d_tail_alt);
         sb->last_n = n;
     }
     PG_HIP(hipEventRecord(sb->ev[1], sb->stream));
