@@ -479,6 +479,41 @@ def test_fused_decimator_with_a_ragged_last_channel_group(gpu_lib, oracle_mod):
     assert names[1] == "k_mix_dec_fused" and names[4] == "k_mix_dec_fused" and names[2] != "k_mix_dec_fused"
 
 
+def test_bank_oscillators_advanced_on_the_device_stay_on_the_oracle_over_many_calls(gpu_lib, oracle_mod):
+    """A bank too large for kernel-argument transport (> 8 channels) carries its oscillators' phases ON the device from call to
+    call (OscAdvance in the tail-refresh launch; the host only mirrors them).  Sixty calls of one super-frame, frequencies that
+    are not multiples of anything convenient, a change of call length half-way (the per-channel advance table is rebuilt) and a
+    retune: the last calls still meet the bar against an oracle that has run the whole stream."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 24
+    fcs = [-800e3 + 66123.457 * c for c in range(C)]
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    for c, fc in enumerate(fcs):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fc); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    check = (0, 7, 23)
+    refs = {}
+    for c in check:
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fcs[c]); r.set_filter(300, 3000)
+        refs[c] = r
+    lens = [1] * 30 + [2] * 15
+    total = sum(lens) * sf
+    x = tones(fs, total, [(0.01, fcs[c] + 900.0 + 13.0 * c, 0.3 * c) for c in range(C)]) + lcg_noise(total, 5, 1e-3)
+    off = 0
+    for k, ln in enumerate(lens):
+        if k == 20:
+            fcs[7] += 250.0
+            rx.set_mixer(7, fcs[7]); refs[7].set_mixer(fcs[7])
+        seg = x[off:off + ln * sf]
+        g = rx.process(seg)[0]
+        for c in check:
+            want = np.concatenate([refs[c].process(seg[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(len(seg) // n)])
+            if k >= len(lens) - 3 or k in (0, 19, 20, 21, 30, 31):
+                assert rel_rms(g[c], want) <= TOL, (k, c)
+        off += ln * sf
+
+
 def test_config4_cic3_chain_mixed_am_usb(gpu_lib, oracle_mod):
     """BASELINE config 4 at parity size: 100 Msps shared input, chain cic3x16,hb11x16,hb15,hb23,hb47 (D = 2048),
     AM on even / USB on odd channels, 4 channels, 2 super-frames.  Oracle frame N = 49152 as SURVEY.md 8(d) prescribes
