@@ -298,6 +298,36 @@ def test_wfm_stereo_mode_in_the_receiver(gpu_lib, oracle_mod):
         assert rel_rms(ga[k], ra[k]) <= TOL
 
 
+def test_wfm_bank_with_mono_and_stereo_channels(gpu_lib, oracle_mod):
+    """dmFMM and dmFMS side by side in one WFM bank off a shared stream (the pre-filter switch is per channel)."""
+    import pebblesdr_amd as P
+    fs, n = 2_500_000, 2048
+    rx = P.ReceiverBank(fs, 2, True, True, 0, max_superframes=1)
+    modes = (P.DM_FMM, P.DM_FMS)
+    refs = []
+    for c, m in enumerate(modes):
+        rx.set_mode(c, m); rx.set_mixer(c, 250e3)
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.FMM if m == P.DM_FMM else oracle_mod.FMS); r.set_mixer(250e3)
+        refs.append(r)
+    sf = rx.superframe
+    K = 7
+    x = _fm_stereo_mpx(fs, K * sf) * np.exp(2j * np.pi * 250e3 * np.arange(K * sf) / fs) + lcg_noise(K * sf, 6, 1e-4)
+    want = [[], []]
+    for f in range(K * sf // n):
+        for c in range(2):
+            a, _ = refs[c].process(x[f * n:(f + 1) * n], want_spectrum=False)
+            if len(a):
+                want[c].append(a)
+    for k in range(K):
+        g = rx.process(x[k * sf:(k + 1) * sf])[0]
+        if k >= 4:
+            for c in range(2):
+                assert rel_rms(g[c], want[c][k]) <= TOL, (k, c)
+    # the two channels do differ (the mono path's 75 kHz pre-filter): the switch is really per channel
+    assert rel_rms(g[0], g[1]) > 1e-4
+
+
 @pytest.mark.parametrize("bins", [2048, 4096, 8192, 16384, 32768])
 def test_spectrum_step(gpu_lib, oracle_mod, bins):
     """fftSpectrum: window, pruned zero-pad FFT, unfold, previous-frame averaging, dB, clip."""
