@@ -914,7 +914,7 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         wp.Llp = Llp;
         wp.gain = 0.25f;  // FMDEMOD_GAIN, demod_wfm.cpp:51
         const long long Lx = (long long)L4 + Llp;
-        launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(256), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
+        launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(512), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
                    out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp, (const unsigned char *)d_stereo);
         PG_HIP(hipGetLastError());
         // next call's history = the last Lx samples of (old history | this call's input), into the other buffer; when the

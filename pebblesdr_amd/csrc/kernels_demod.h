@@ -174,7 +174,7 @@ __host__ __device__ inline size_t wfm_fir_lds_bytes(int L4, int Llp)
 }
 
 // xtail: [channel][L4 + Llp] input samples preceding in[0] (zeros before the first call)
-static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ xtail,
+static __global__ __launch_bounds__(512) void k_wfm_fir(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ xtail,
                                                         float2 *__restrict__ out, long long out_pitch, long long n, WfmFirParams wp,
                                                         const float *__restrict__ h, const float *__restrict__ hlp,
                                                         const unsigned char *__restrict__ no_prefilter /* [channel] or null: dmFMS, see WfmCore */)
@@ -194,7 +194,7 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
     if (tid < kWfmLpMax) hl[tid] = tid < Llp ? (raw_iq ? (tid == 0 ? 1.f : 0.f) : hlp[tid]) : 0.f;
     // ---- 1. input samples x0 .. x0+NX-1, x0 = s - L4 - Llp (history from the tail, nothing past n) ----
     const long long x0 = s - Lx;
-    for (int j = tid; j < NX; j += 256) {
+    for (int j = tid; j < NX; j += 512) {
         const long long g = x0 + j;
         float2 v = make_float2(0.f, 0.f);
         if (g < 0) v = xt[Lx + g];
@@ -204,7 +204,7 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
     __syncthreads();
     // ---- 2. low-pass: lpb[k] = sum_m hlp[m] * xs[k + Llp - 1 - m], k < NL.  Work-item: outputs 8a .. 8a+7; with the
     //         pad its 9-slot stride spreads a wave's 8-byte reads over all banks. ----
-    for (int a8 = tid * 8; a8 < NL; a8 += 256 * 8) {
+    for (int a8 = tid * 8; a8 < NL; a8 += 512 * 8) {
         float2 w[8], acc[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -229,7 +229,7 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
     }
     __syncthreads();
     // ---- 3. discriminator d[s - L4 + i], i < ND (demod_wfm.cpp:217) ----
-    for (int i = tid; i < ND; i += 256) {
+    for (int i = tid; i < ND; i += 512) {
         const float2 c0 = lpb[i + 1], c1 = lpb[i];
         db[i] = wp.gain * atan2f(c1.x * c0.y - c0.x * c1.y, c1.x * c0.x + c1.y * c0.y);
     }
@@ -237,22 +237,29 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
     // ---- 4. y[s + 4 tid + r] = sum_p h[p] * d[s + 4 tid + r - p] ----
     //         Taps are fetched 16 at a time, one chunk (64 FMAs per work-item) ahead of their use, with VECTOR loads of
     //         a lane-invariant address: scalar loads share the LDS wait counter and return out of order, which would
-    //         force a full wait at every LDS read.  The next history block is read from LDS one group ahead.
-    const float4 *blk = reinterpret_cast<const float4 *>(db) + tid + (L4 >> 2);
+    //         force a full wait at every LDS read; taps parked in LDS cost four 16-byte broadcast reads per chunk and per
+    //         wave (measured: 0.027 -> 0.040 ms).  The next history block is read from LDS one group ahead.
+    //         The workgroup's two halves split the taps: work-items 0..255 run p in [0, L4/2) rounded to 16, 256..511 the rest, and
+    //         the halves' fp64 partial sums meet in LDS (this kernel runs on an otherwise idle GPU behind the display transform:
+    //         its own serial length is the call's time).
+    const int half = tid >> 8, ot = tid & 255;
+    const int p_split = ((L4 >> 1) + 15) & ~15;
+    const int p_lo = half ? p_split : 0, p_hi = half ? L4 : p_split;
+    const float4 *blk = reinterpret_cast<const float4 *>(db) + ot + (L4 >> 2) - (p_lo >> 2);
     float4 cur = blk[0], nxt = blk[-1];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     int vz = 0;
     opaque(vz);  // a zero the compiler must treat as per-lane: keeps the tap loads on the vector memory path
-    const float *hv = h + vz;
-    float hn[16];
+    const float4 *hv = reinterpret_cast<const float4 *>(h) + vz;  // (16-byte loads: four per chunk)
+    float4 hn[4];
 #pragma unroll
-    for (int u = 0; u < 16; u++) hn[u] = hv[u];
-    for (int p0 = 0; p0 < L4; p0 += 16) {  // L4 is a multiple of 16; h carries 16 zeros past it
+    for (int u = 0; u < 4; u++) hn[u] = hv[(p_lo >> 2) + u];
+    for (int p0 = p_lo; p0 < p_hi; p0 += 16) {  // L4 is a multiple of 16; h carries 16 zeros past it
         float ht[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) ht[u] = hn[u];
+        for (int u = 0; u < 4; u++) { ht[4 * u] = hn[u].x; ht[4 * u + 1] = hn[u].y; ht[4 * u + 2] = hn[u].z; ht[4 * u + 3] = hn[u].w; }
 #pragma unroll
-        for (int u = 0; u < 16; u++) hn[u] = hv[p0 + 16 + u];
+        for (int u = 0; u < 4; u++) hn[u] = hv[((p0 + 16) >> 2) + u];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -268,11 +275,20 @@ static __global__ __launch_bounds__(256) void k_wfm_fir(const float2 *__restrict
         }
         acc[0] += (double)a0; acc[1] += (double)a1; acc[2] += (double)a2; acc[3] += (double)a3;
     }
-    float2 *y = out + (long long)c * out_pitch + s + 4 * tid;
+    // the second half's sums through LDS (xs is free: every work-item is past the low-pass), added in the first half
+    __syncthreads();
+    double *part = reinterpret_cast<double *>(xs);
+    if (half) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[r * 256 + ot] = acc[r];
+    }
+    __syncthreads();
+    if (half) return;
+    float2 *y = out + (long long)c * out_pitch + s + 4 * ot;
 #pragma unroll
     for (int r = 0; r < 4; r++)
-        if (s + 4 * tid + r < n) {
-            const float v = (float)acc[r];
+        if (s + 4 * ot + r < n) {
+            const float v = (float)(acc[r] + part[r * 256 + ot]);
             y[r] = make_float2(v, v);  // mono: left = right (demod_wfm.cpp:229-230)
         }
 }
