@@ -557,7 +557,11 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (casc.nst > 0) {
         rest_name = wide && !fused_front ? "k_fir_dec + k_cascade" : "k_cascade";
         len_out = n / (long long)chain.total;
-        launch_lds(k_cascade, dim3(cdiv(len_out, casc.outb), C), dim3(256), casc_lds_bytes, s, (const float2 *)src->data(), src->pitch, fin.data(),
+        const bool three2 = casc.nst == 3 && casc.stride[0] == 2 && casc.stride[1] == 2 && casc.stride[2] == 2;
+        auto kern = k_cascade<0, 0, 0>;
+        if (three2 && casc.ntaps[0] == 15 && casc.ntaps[1] == 23 && casc.ntaps[2] == 47) kern = k_cascade<15, 23, 47>;  // WFM from 20 Msps, narrow from 100 Msps
+        else if (three2 && casc.ntaps[0] == 15 && casc.ntaps[1] == 19 && casc.ntaps[2] == 31) kern = k_cascade<15, 19, 31>;  // narrow at 2.048 Msps
+        launch_lds(kern, dim3(cdiv(len_out, casc.outb), C), dim3(256), casc_lds_bytes, s, (const float2 *)src->data(), src->pitch, fin.data(),
                    fin.pitch, len_out, casc);
     }
     PG_HIP(hipGetLastError());

@@ -224,6 +224,11 @@ static __global__ __launch_bounds__(256) void k_mix_dec1(const float2 *__restric
 // first stage-0 output of this call; what lies before it (head-room) is the previous call's tail, deep enough for
 // the whole cascade: halo0 = sum_s (T_s - 1) * prod_{r<s} S_r.
 // grid (ceil(n_out/outb), C); dynamic LDS = (count_0 + count_1) float2.
+// F0, F1, F2 > 0: a chain of exactly three stride-2 stages with these tap counts (the one-channel WFM chain hb15, hb23, hb47 runs
+// behind the display transform on an idle GPU, so its length is the call's): the tap loops unroll and the taps come straight out
+// of the kernel arguments as scalars -- the generic form reads every tap from LDS next to every sample, and its three stages took
+// 13 of the kernel's 24 us.  F0 = 0: any chain.
+template <int F0, int F1, int F2>
 static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict__ in, long long in_pitch,
                                                          float2 *__restrict__ out, long long out_pitch, long long n_out,
                                                          CascadeParams cp)
@@ -279,6 +284,28 @@ static __global__ __launch_bounds__(256) void k_cascade(const float2 *__restrict
             const int S = cp.stride[s], T = cp.ntaps[s], ns = cnt[s + 1];
             const bool last = s == cp.nst - 1;
             const int cc = (T - 1) >> 1;  // halfband: even taps + the odd centre
+            if (F0 > 0 && s < 3) {
+                constexpr int TF[3] = {F0 > 0 ? F0 : 3, F1 > 0 ? F1 : 3, F2 > 0 ? F2 : 3};
+                auto fixed = [&](auto tc) {
+                    constexpr int TT = decltype(tc)::value, CC = (TT - 1) >> 1;
+                    for (int j = t; j < ns; j += 256) {
+                        const float2 *w = src + j * 2;
+                        float2 acc = cscale(w[CC], cp.h[s][CC]);
+#pragma unroll
+                        for (int p = 0; p < TT; p += 2) {
+                            const float h = cp.h[s][p];
+                            const float2 m = w[p];
+                            acc.x = fmaf(m.x, h, acc.x);
+                            acc.y = fmaf(m.y, h, acc.y);
+                        }
+                        if (last) out[(long long)c * out_pitch + o0 + j] = cscale(acc, cp.gain);
+                        else dst[j] = acc;
+                    }
+                };
+                if (s == 0) fixed(std::integral_constant<int, TF[0]>{});
+                else if (s == 1) fixed(std::integral_constant<int, TF[1]>{});
+                else fixed(std::integral_constant<int, TF[2]>{});
+            } else
             for (int j = t; j < ns; j += 256) {
                 const float2 *w = src + j * S;
                 float2 acc = cscale(w[cc], ht[s][cc]);
