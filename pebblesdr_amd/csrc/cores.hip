@@ -582,21 +582,26 @@ void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
     if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
 }
 
-int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa)
+int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa)
 {
-    const bool adv = oa != nullptr && oa->osc != nullptr;
-    if (jobs.empty() && !adv) return 0;
     if (jobs.size() > (size_t)kMaxTailJobs) return fail(PEBBLEGPU_E_INVALID, "too many history buffers");
-    TailJobs tj;
     memset(&tj, 0, sizeof(tj));
     tj.count = (int)jobs.size();
-    if (adv) tj.oa = *oa;
+    if (oa != nullptr && oa->osc != nullptr) tj.oa = *oa;
     int maxh = 1;
     for (size_t i = 0; i < jobs.size(); i++) {
         tj.job[i] = jobs[i];
         if (jobs[i].hist > maxh) maxh = jobs[i].hist;
     }
     if (maxh > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "history of %d samples too deep for the tail refresh", maxh);
+    return 0;
+}
+int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa)
+{
+    const bool adv = oa != nullptr && oa->osc != nullptr;
+    if (jobs.empty() && !adv) return 0;
+    TailJobs tj;
+    if (int rc = fill_tail_jobs(tj, jobs, oa)) return rc;
     launch(k_save_tails, dim3(1, channels, (unsigned)(jobs.empty() ? 1 : jobs.size())), dim3(256), s, tj);
     PG_HIP(hipGetLastError());
     return 0;
@@ -901,8 +906,10 @@ int WfmCore::set_stereo(uint32_t ch, bool on)
     stereo[ch] = on;
     return 0;
 }
-int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n)
+int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n,
+                 const std::vector<TailJob> *more_tails, const OscAdvance *oa, bool *carried)
 {
+    if (carried) *carried = false;
     if (n < kMaxTaps) return fail(PEBBLEGPU_E_SIZE, "WFM demod needs at least %d samples per call", kMaxTaps);
     last_n = n;
     if (stereo_dirty) {  // (rare: a mode change)
@@ -918,17 +925,34 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         wp.Llp = Llp;
         wp.gain = 0.25f;  // FMDEMOD_GAIN, demod_wfm.cpp:51
         const long long Lx = (long long)L4 + Llp;
-        launch_lds(k_wfm_fir, dim3(cdiv(n, kWfmOutB), C), dim3(512), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
-                   out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp, (const unsigned char *)d_stereo);
-        PG_HIP(hipGetLastError());
         // next call's history = the last Lx samples of (old history | this call's input), into the other buffer; when the
-        // call alone covers it the copy rides on the caller's tail-refresh launch (tail_jobs)
+        // call alone covers it the copy is a tail-refresh job (tail_jobs): carried by this launch when the caller hands over
+        // its own jobs, else left to the caller's tail-refresh launch
         float2 *nt = d_xtail[parity ^ 1];
         deferred_in = nullptr;
         if (n >= Lx) {
             deferred_in = in;
             deferred_pitch = in_pitch;
-        } else {
+        }
+        const int groups = (int)cdiv(n, kWfmOutB);
+        TailJobs tj;
+        memset(&tj, 0, sizeof(tj));
+        int extra = 0;
+        if (more_tails != nullptr && n >= Lx) {
+            std::vector<TailJob> jobs(*more_tails);
+            jobs.push_back(TailJob{const_cast<float2 *>(in), in_pitch, n, (int)Lx, 0, nt, Lx});
+            if (fill_tail_jobs(tj, jobs, oa) == 0) {
+                extra = (int)jobs.size();
+                if (carried) *carried = true;
+                deferred_in = nullptr;  // (done here)
+            } else {
+                memset(&tj, 0, sizeof(tj));
+            }
+        }
+        launch_lds(k_wfm_fir, dim3(groups + extra, C), dim3(512), wfm_fir_lds_bytes(L4, Llp), s, in, in_pitch, (const float2 *)d_xtail[parity],
+                   out, out_pitch, n, wp, (const float *)d_h, (const float *)d_hlp, (const unsigned char *)d_stereo, groups, tj);
+        PG_HIP(hipGetLastError());
+        if (n < Lx) {
             PG_HIP(hipMemcpy2DAsync(nt, sizeof(float2) * Lx, d_xtail[parity] + n, sizeof(float2) * Lx, sizeof(float2) * (Lx - n), C, hipMemcpyDeviceToDevice, s));
             PG_HIP(hipMemcpy2DAsync(nt + (Lx - n), sizeof(float2) * Lx, in, sizeof(float2) * in_pitch, sizeof(float2) * n, C, hipMemcpyDeviceToDevice, s));
         }

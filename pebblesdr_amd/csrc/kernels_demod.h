@@ -12,6 +12,7 @@
 // so the pole radius^samples < 1e-13, else it selects the exact sequential mode, warm_sub < 0).
 #pragma once
 #include "params.h"
+#include "tail_refresh.h"
 
 namespace pg {
 
@@ -177,8 +178,13 @@ __host__ __device__ inline size_t wfm_fir_lds_bytes(int L4, int Llp)
 static __global__ __launch_bounds__(512) void k_wfm_fir(const float2 *__restrict__ in, long long in_pitch, const float2 *__restrict__ xtail,
                                                         float2 *__restrict__ out, long long out_pitch, long long n, WfmFirParams wp,
                                                         const float *__restrict__ h, const float *__restrict__ hlp,
-                                                        const unsigned char *__restrict__ no_prefilter /* [channel] or null: dmFMS, see WfmCore */)
+                                                        const unsigned char *__restrict__ no_prefilter /* [channel] or null: dmFMS, see WfmCore */,
+                                                        int n_fir_groups, TailJobs tails /* run by the workgroups behind the first n_fir_groups: the call's tail refresh rides on this launch */)
 {
+    if ((int)blockIdx.x >= n_fir_groups) {  // (none of what these jobs write is read by the demodulator's workgroups)
+        save_tails_block(tails, (int)blockIdx.x - n_fir_groups, (int)blockIdx.y, (int)threadIdx.x);
+        return;
+    }
     HIP_DYNAMIC_SHARED(float2, dyn)
     const int L4 = wp.L4, Llp = wp.Llp;
     const int ND = kWfmOutB + L4, NL = (ND + 1 + 7) & ~7, NX = NL + Llp - 1, Lx = L4 + Llp;

@@ -11,6 +11,7 @@
 // channel for the first stage; later stages (8 + 8/stride) B per their own input sample.
 #pragma once
 #include "params.h"
+#include "tail_refresh.h"
 
 namespace pg {
 
@@ -814,33 +815,7 @@ static __global__ __launch_bounds__(256) void k_gate_zero(float2 *__restrict__ a
 // it will write.  grid (1, C, jobs), hist <= 256*32.
 static __global__ __launch_bounds__(256) void k_save_tails(TailJobs jobs)
 {
-    if (jobs.oa.osc != nullptr && blockIdx.z == 0 && threadIdx.x == 0 && blockIdx.y < jobs.oa.osc_count) {
-        // OscBank::advance (Mixer's carried phase, mixer.cpp:48-81 in closed form): every later kernel of the stream sees it
-        ChanOsc &o = jobs.oa.osc[blockIdx.y];
-        double p = o.phase0 + jobs.oa.adv[blockIdx.y];
-        p -= floor(p);
-        o.phase0 = p >= 1.0 ? 0.0 : p;
-        const uint32_t n0 = o.n0 + jobs.oa.adv_n;
-        o.n0 = n0 > (uint32_t)kAmpTab ? (uint32_t)kAmpTab : n0;
-    }
-    if ((int)blockIdx.z >= jobs.count) return;  // (an advance-only launch)
-    const TailJob &tj = jobs.job[blockIdx.z];
-    float2 *b = tj.data + (long long)blockIdx.y * tj.pitch;
-    float2 keep[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const int j = threadIdx.x + 256 * k;
-        if (j < tj.hist) keep[k] = b[tj.n - tj.hist + j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const int j = threadIdx.x + 256 * k;
-        if (j < tj.hist) {
-            if (tj.dst) tj.dst[(long long)blockIdx.y * tj.dst_pitch + j] = keep[k];
-            else b[-tj.hist + j] = keep[k];
-        }
-    }
+    save_tails_block(jobs, (int)blockIdx.z, (int)blockIdx.y, (int)threadIdx.x);
 }
 
 }  // namespace pg

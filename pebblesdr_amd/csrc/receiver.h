@@ -37,6 +37,7 @@ int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa = nullptr);
+int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa);  // 0, or a failure code (too many / too deep)
 int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale = 0.f);
 int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
                   int stride, uint32_t channels);
@@ -204,7 +205,11 @@ struct WfmCore {
     int set_stereo(uint32_t ch, bool on);
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
-    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n);
+    // more_tails / oa: the caller's other tail-refresh jobs and oscillator advance; when the single-kernel path runs it carries
+    // them (and its own history copy) in extra workgroups of its launch and sets *carried -- the caller then skips its own
+    // tail-refresh launch (one launch and ~5 us fewer on the call's critical path)
+    int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n,
+            const std::vector<TailJob> *more_tails = nullptr, const OscAdvance *oa = nullptr, bool *carried = nullptr);
     void tail_jobs(std::vector<TailJob> &jobs) const;
     long long last_n = 0;
 };

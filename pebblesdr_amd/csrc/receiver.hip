@@ -391,7 +391,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     }
     // Squelch, receiver.cpp:893-897 / :962-965: below the threshold the reference returns here -- nothing behind the gate
     // runs or changes state, and no audio leaves the call.
-    bool gate_closed = false;
+    bool gate_closed = false, tails_carried = false;
     if (squelch_db_ > -120.0) {
         if (!last_spec_frames) return fail(PEBBLEGPU_E_INVALID, "the squelch gate needs a spectrum: none has been computed yet");
         PG_HIP(hipMemcpyAsync(h_gate_, d_smeter + (last_spec_frames - 1), sizeof(float4), hipMemcpyDeviceToHost, cs));
@@ -442,7 +442,12 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             if (ctl_[ch].mode == PEBBLEGPU_DM_NONE) PG_HIP(hipMemsetAsync(audio.data((int)ch), 0, sizeof(float2) * (size_t)nd, cs));
     } else {
         if (profile_detail) PG_HIP(hipEventRecord(ev[4], cs));
-        if (int rc = wfmc_.run(cs, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd)) return rc;  // receiver.cpp:896
+        // (the call's tail refresh rides on the demodulator's launch: it is the last kernel of the call, run on an idle GPU)
+        std::vector<TailJob> jobs;
+        dec_.tail_jobs(jobs);
+        OscAdvance oa;
+        if (int rc = osc_.advance_job(cs, n, &oa)) return rc;
+        if (int rc = wfmc_.run(cs, dec_.out().data(), dec_.out().pitch, audio.data(), audio.pitch, nd, &jobs, &oa, &tails_carried)) return rc;  // receiver.cpp:896
     }
     if (!gate_closed) {
         last_audio_n = (uint64_t)nd;
@@ -453,7 +458,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         }
     }
     if (profile_detail) PG_HIP(hipEventRecord(ev[5], cs));
-    {  // one launch refreshes every history head-room for the next call
+    if (!tails_carried) {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
