@@ -86,6 +86,15 @@ __device__ __forceinline__ float2 cmul_pk(float2 c, float2 x)
     const v2f_t r = cmul_pk(v2f_t{c.x, c.y}, v2f_t{x.x, x.y});
     return make_float2(r.x, r.y);
 }
+// the same with a wave-uniform c held in a scalar register pair (one scalar operand per instruction: the constant bus limit)
+__device__ __forceinline__ float2 cmul_pk_s(float2 c, float2 x)
+{
+    const v2f_t cc = {c.x, c.y}, xx = {x.x, x.y};
+    v2f_t r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(r) : "s"(cc), "v"(xx));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(r) : "s"(cc), "v"(xx));
+    return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ v2f_t cmac_pk(v2f_t acc, v2f_t c, v2f_t x)
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(c), "v"(x));

@@ -1350,6 +1350,7 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     // shared-frame kernels on the bench batch it wins at 2048 bins (0.098 vs 0.105 ms) and loses at 4096 (0.198 vs 0.185) and
     // 8192 (0.44 vs 0.28: its ZP workgroups each re-read the frame and store 4-byte bins ZP*4 bytes apart), so it runs where
     // it wins and where nothing else exists (16384, 32768).  PEBBLEGPU_SPECTRUM_PERQ=1 forces it everywhere (A/B runs).
+    { const char *e = getenv("PEBBLEGPU_SPECTRUM_W64"); use_w64 = e && e[0] == '1'; }  // the one-wave 8192-bin kernel (measured equal: opt-in)
     const char *env = getenv("PEBBLEGPU_SPECTRUM_PERQ");
     per_q = !big && (bins == 2048 || bins > 8192 || (env && env[0] == '1'));
     std::vector<double> w;
@@ -1467,6 +1468,29 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         static const bool f_regs = [] { const char *e = getenv("PEBBLEGPU_SPECTRUM_FREGS"); return e && e[0] == '1'; }();
         launch(f_regs ? k_spectrum_q128<true> : k_spectrum_q128<false>, dim3((unsigned)(8 * zp * cdiv(chains, 8)), S), dim3(128), s, d_in, d_out, (const float2 *)d_ftab, (const float2 *)d_tw128,
                (const float *)d_prev[parity], d_prev[parity ^ 1], sp, zl);
+        parity ^= 1;
+        PG_HIP(hipGetLastError());
+        return 0;
+    }
+    if (bins == 8192 && use_w64) {
+        // one-wave transforms (fft_w64.h), one frame chain per 256-item workgroup, two workgroups per CU: chains as long as
+        // keeps every workgroup resident at once (every chain recomputes one frame)
+        long long Gw = cdiv(F * (long long)S, 512);
+        Gw = Gw < 1 ? 1 : (Gw > 32 ? 32 : Gw);
+        sp.frames_per_group = (int)Gw;
+        sp.scale = scale;
+        sp.out_pitch = F * (long long)bins;
+        const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
+        const dim3 grid((unsigned)cdiv(F, Gw), S), block(256);
+        auto go = [&](auto kern) { launch(kern, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab, (const float *)d_prev[parity], d_prev[parity ^ 1], sp, rs); };
+        switch (raw ? raw->fmt : -1) {
+        case -1: go(k_spectrum_w64<-1>); break;
+        case 0: go(k_spectrum_w64<0>); break;
+        case 1: go(k_spectrum_w64<1>); break;
+        case 2: go(k_spectrum_w64<2>); break;
+        case 3: go(k_spectrum_w64<3>); break;
+        default: go(k_spectrum_w64<4>); break;
+        }
         parity ^= 1;
         PG_HIP(hipGetLastError());
         return 0;

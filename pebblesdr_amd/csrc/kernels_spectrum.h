@@ -33,6 +33,7 @@
 #pragma once
 #include "fft_lds.h"
 #include "fft_t128.h"
+#include "fft_w64.h"
 #include "params.h"
 
 namespace pg {
@@ -333,6 +334,185 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     }
     if (HALVES > 1 && half == 0)
         for (int i = 0; i < shift; i++) __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8192 bins on the ONE-wave transform of fft_w64.h (radix 32 * 4 * 16: the middle pass on lane swaps, one LDS exchange).
+//
+// A 256-item workgroup = the four transforms (q = wave) of one frame at a time, a chain of G frames.  Per frame and wave: 32
+// samples from the parked frame, the wave-uniform pre-twiddle W_128^{n1 q} (scalar operands), the transform in the wave's own
+// 8.5 KiB image (no barrier inside), amplitude / average / dB, the dB values parked in that same image; then all four waves
+// store 16-byte groups of the four q.  TWO workgroup barriers per frame against seven in k_spectrum_t128, 5.2 M LDS instructions
+// per bench step against 8.6 M, the same 77 M vector instructions -- and the same time: at 1.3 kW the chip is at its power limit
+// under either kernel, and the clock gives back whatever the schedule gains (profiles/r02_power_clock.txt).
+// Opt-in (PEBBLEGPU_SPECTRUM_W64=1): two workgroups per CU (51 KiB of LDS, 164 registers) leave room for the chain's LDS
+// kernels beside them, which k_spectrum_t128's 152 KiB do not.  grid (ceil(F / G), S), block 256.
+// ------------------------------------------------------------------------------------------------
+template <int FMT>
+static __global__ __launch_bounds__(256, 2) void k_spectrum_w64(const float2 *__restrict__ in, float *__restrict__ out, const float *__restrict__ window,
+                                                                 const float2 *__restrict__ btab, const float *__restrict__ prev_in,
+                                                                 float *__restrict__ prev_out, SpectrumParams sp, RawSrc raw)
+{
+    constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 32, QSTRIDE = kW64ImageSlots * 2;
+    constexpr bool RAW = FMT >= 0;
+    __shared__ float2 frame[NF];
+    __shared__ float2 img[ZP][kW64ImageSlots];
+    __shared__ float2 stab[ZP][32];  // W_128^{n1 q}: the wave-uniform part of the pre-twiddle W_8192^{n q}, n = 64 n1 + lane
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6), s = blockIdx.y;
+    const int G = sp.frames_per_group;
+    const long long f0 = (long long)blockIdx.x * G;
+    const float2 *x = in + (long long)s * sp.in_pitch;
+    float *y = out + (long long)s * sp.out_pitch;
+    // a work-item parks samples tid + 256 i (RAW: 4 tid + 1024 (i >> 2) + (i & 3): two runs of four adjacent samples)
+    const W64Consts c = w64_consts(lane, cis_cycles(-(double)(lane * q) / (double)BINS));
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
+    const int kb = w64_kbase(lane);
+    if (tid < ZP * 32) stab[tid >> 5][tid & 31] = btab[tid];
+    float pa[E];
+    float2 xn[8];
+    float win[8];
+#ifdef PG_W64_PROFILE  // tools/ubench/spectrum_phases.hip: cycles per phase of the frame loop, summed per wave (raw.base = the output table)
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;
+#define PG_W64_TICK(i) { const long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tl; tl = t_; }
+#else
+#define PG_W64_TICK(i)
+#endif  // fetched with the frame (L1 hits) rather than held through the transform: the registers are needed there
+    auto fetch_window = [&](int td) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[i] = RAW ? window[4 * td + 1024 * (i >> 2) + (i & 3)] : window[td + 256 * i];
+    };
+    auto fetch_frame = [&](long long ff, int td) {
+        if (RAW) {
+            const long long i0 = (long long)s * sp.in_pitch + ff * NF + 4 * td;
+            float2 a[4], b[4];
+            raw_load4<FMT < 0 ? 0 : FMT>(raw, i0, a);
+            raw_load4<FMT < 0 ? 0 : FMT>(raw, i0 + 1024, b);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { xn[i] = a[i]; xn[4 + i] = b[i]; }
+        } else {
+            const float2 *xp = x + ff * NF + td;
+#pragma unroll
+            for (int i = 0; i < 8; i++) xn[i] = xp[256 * i];
+        }
+    };
+    auto park = [&](int td) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) frame[RAW ? 4 * td + 1024 * (i >> 2) + (i & 3) : td + 256 * i] = cscale(xn[i], win[i]);
+    };
+    {
+        const long long ff = f0 > 0 ? f0 - 1 : 0;
+        if (ff < sp.n_frames) {
+            fetch_frame(ff, tid);
+            fetch_window(tid);
+            park(tid);
+        }
+    }
+    __syncthreads();
+#ifdef PG_W64_PROFILE
+    tl = __builtin_readcyclecounter();
+#endif
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        const bool live = f < sp.n_frames;   // workgroup-uniform
+        const bool xform = live && f >= 0;
+        int ln = lane, td = tid, qq = q;
+        opaque(ln);
+        opaque(td);
+        asm volatile("" : "+s"(qq));
+        const bool fetch = it + 1 < G && f + 1 < sp.n_frames && f >= 0;
+        // the next frame is requested whether or not it will be used (a clamped index, no branch): a conditional request is a
+        // block of its own that the compiler moves up into the transform, where its registers do not exist
+        const long long fnext = f + 1 < sp.n_frames ? (f + 1 > 0 ? f + 1 : 0) : sp.n_frames - 1;
+        fetch_frame(fnext, td);  // (164 registers: two such workgroups leave a SIMD 176 for the chain's kernels beside them)
+        if (live && f < 0) {
+            int kq = ZP * kb + q;
+            opaque(kq);  // (addresses of the two rare paths are not worth 64 registers across the loop)
+            const float *pp = prev_in + (long long)s * BINS + kq;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k3 = 0; k3 < 16; k3++) pa[16 * h + perm16(k3)] = pp[ZP * (32 * h + 128 * k3)];
+        }
+        if (xform) {
+            float2 v[E];
+            const float2 *gp = frame + ln;
+            const float2 *sq = stab[qq];  // one address for the whole wave: a broadcast read, two registers until the product
+            v[0] = gp[0];
+#pragma unroll
+            for (int m = 1; m < E; m++) v[m] = cmul_pk(sq[m], gp[64 * m]);
+            PG_W64_TICK(0)
+            fft2048_w64(v, img[q], c, ln);
+            PG_W64_TICK(1)
+            sched_fence();
+            fetch_window(td);  // (L1 hits; not held through the transform: the registers are needed there)
+            sched_fence();
+            float *st = reinterpret_cast<float *>(img[q]) + w64_kbase(ln);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {  // eight values at a time: they are in flight together, not all 32
+                constexpr int NG = 8;
+                const int h = g >> 1, kk = (g & 1) * NG;
+                float mag[NG];
+#pragma unroll
+                for (int m = 0; m < NG; m++) {
+                    const float2 z = v[16 * h + perm16(kk + m)];
+                    mag[m] = z.x * z.x + z.y * z.y;
+                }
+#pragma unroll
+                for (int m = 0; m < NG; m++) mag[m] = __builtin_amdgcn_sqrtf(mag[m]);
+#pragma unroll
+                for (int m = 0; m < NG; m++) {
+                    const float a = mag[m] + pa[16 * h + perm16(kk + m)];
+                    pa[16 * h + perm16(kk + m)] = mag[m];
+                    mag[m] = a;
+                }
+#pragma unroll
+                for (int m = 0; m < NG; m++) mag[m] = __builtin_amdgcn_logf(mag[m]);
+#pragma unroll
+                for (int m = 0; m < NG; m++)
+                    st[32 * h + 128 * (kk + m)] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);
+                sched_fence();
+            }
+            if (f == sp.n_frames - 1) {
+                int kq = ZP * kb + q;
+                opaque(kq);
+                float *pp = prev_out + (long long)s * BINS + kq;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int k3 = 0; k3 < 16; k3++) pp[ZP * (32 * h + 128 * k3)] = pa[16 * h + perm16(k3)];
+            }
+        }
+        PG_W64_TICK(2)
+        __syncthreads();  // B: dB values parked, the frame consumed
+        PG_W64_TICK(3)
+        if (fetch) park(td);
+        if (it >= 0 && live) {
+            // bins j, j + 1 (j = 2 td + 512 i) of the four q: four 8-byte reads, two adjacent 16-byte stores
+            const float2 *sp0 = reinterpret_cast<const float2 *>(img[0]) + td;
+            float *yf = y + f * (long long)BINS;
+#pragma unroll
+            for (int i = 0; i < NF / 512; i++) {
+                const int j = 2 * td + 512 * i;
+                const float2 d0 = sp0[0 * (QSTRIDE / 2) + 256 * i], d1 = sp0[1 * (QSTRIDE / 2) + 256 * i];
+                const float2 d2 = sp0[2 * (QSTRIDE / 2) + 256 * i], d3 = sp0[3 * (QSTRIDE / 2) + 256 * i];
+                // bin k = ZP*j + q unfolds to (k + BINS/2) mod BINS (fft.cpp:207-213); j is even: the pair never straddles the fold
+                float4 *dst = reinterpret_cast<float4 *>(yf + ((ZP * j + BINS / 2) & (BINS - 1)));
+                dst[0] = make_float4(d0.x, d1.x, d2.x, d3.x);
+                dst[1] = make_float4(d0.y, d1.y, d2.y, d3.y);
+            }
+        }
+        PG_W64_TICK(4)
+        __syncthreads();  // C: next frame parked, dB values consumed
+        PG_W64_TICK(5)
+    }
+#ifdef PG_W64_PROFILE
+    if (lane == 0) {
+        long long *o = reinterpret_cast<long long *>(const_cast<void *>(raw.base)) + ((long long)blockIdx.x * 4 + q) * 8;
+        for (int i = 0; i < 8; i++) o[i] = tacc[i];
+    }
+#endif
+#undef PG_W64_TICK
 }
 
 // ------------------------------------------------------------------------------------------------

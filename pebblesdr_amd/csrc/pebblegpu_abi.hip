@@ -232,9 +232,16 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
         if (which >= 2 && !t.detailed[(t.calls - 1 - k) % pg::Timers::kRing])
             return fail(PEBBLEGPU_E_INVALID, "per-kernel times need pebblegpu_receiver_set_profiling(rx, 1) before the calls");
         float one = 0;
+        const bool has_mid = t.has_mid[(t.calls - 1 - k) % pg::Timers::kRing];
         PG_HIP(hipEventSynchronize(ev[6]));
-        if (which == 1 && !t.has_mid[(t.calls - 1 - k) % pg::Timers::kRing]) continue;  // no display transform in that call: 0 ms
+        if (has_mid) PG_HIP(hipEventSynchronize(ev[1]));  // pipelined calls: the transform's stream ends on its own
+        if (which == 1 && !has_mid) continue;  // no display transform in that call: 0 ms
         PG_HIP(hipEventElapsedTime(&one, ev[a[which]], ev[b[which]]));
+        if (which == 0 && has_mid) {  // the call lasted until the later of its two pipelines
+            float other = 0;
+            PG_HIP(hipEventElapsedTime(&other, ev[0], ev[1]));
+            if (other > one) one = other;
+        }
         sum += one;
     }
     *ms = (float)(sum / last_k);

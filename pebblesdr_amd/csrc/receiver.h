@@ -296,6 +296,7 @@ struct SpectrumCore {
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
     float2 *d_btab128 = nullptr, *d_tw128 = nullptr;  // the same for the two-wave transform (fft_t128.h), 8192 bins
     float2 *d_ftab = nullptr;         // [bins/nf][nf] window[n] * W_bins^{n q}: the one factor per point of k_spectrum_q128
+    bool use_w64 = false;             // 8192 bins on k_spectrum_w64 (PEBBLEGPU_SPECTRUM_W64=1 when the core is created)
     int stagger = 0, pad_lds = 0;     // k_spectrum_t128: barrier intervals between the two halves of a 1024-item workgroup (0: 512-item workgroups)
     bool per_q = false;               // k_spectrum_q128 (one transform per 128-item workgroup) instead of the shared-frame kernels
     // 65536-sample frames / 65536 bins (four-step, kernels_spectrum.h): the [S][F][32][2048] intermediate
@@ -381,7 +382,7 @@ private:
         double lo = 0, hi = 0, am_bw = 16000;  // Demod_AM ctor default (demod_am.cpp:9)
         bool bp_valid = false, bp_dirty = false, am_dirty = true;
     };
-    int apply_controls();
+    int apply_controls(hipStream_t osc_stream);
     std::mutex mu_;
     hipStream_t stream_ = nullptr;
     // The display transform is arithmetic-bound and the front of the chain memory-bound: when the chain's first kernel
@@ -391,6 +392,9 @@ private:
     // No events of its own: the chain stream waits for the call's start event, the call's end event is recorded on the chain
     // stream once it has also seen the transform's end event, and whatever next touches the main stream (the next call, a
     // synchronise) first waits for that end event.  Every event record costs the stream ~5 us, so none is spent on the fork/join.
+    hipEvent_t spec_end_ = nullptr;   // pipelined calls: the last display transform queued on the main stream (for the chain's stream to wait on at a join)
+    bool pipeline_ = false;           // successive side-by-side calls overlap (PEBBLEGPU_PIPELINE=1 when the receiver is created)
+    bool touched_ = true;             // a setter ran since the last call
     hipEvent_t chain_end_ = nullptr;  // set when a two-stream call failed half-way: what was queued on the chain stream, for the main stream to wait on
     std::vector<ChanCtl> ctl_;
     bool am_list_dirty_ = true, sm_dirty_ = true;

@@ -30,6 +30,7 @@ int Receiver::create(const pebblegpu_config *cfg)
     PG_HIP(hipSetDevice(device));
     PG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     PG_HIP(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
+    { const char *e = getenv("PEBBLEGPU_PIPELINE"); pipeline_ = e && e[0] == '1'; }
     for (auto &row : tm.ev)
         for (auto &e : row) PG_HIP(hipEventCreate(&e));
 
@@ -117,6 +118,7 @@ int Receiver::set_mixer(uint32_t ch, double f)
 {
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     osc_.retune(ch, f);
     sm_dirty_ = true;
     return 0;
@@ -128,6 +130,7 @@ int Receiver::set_mode(uint32_t ch, int mode)
     if (wfm) {
         if (mode != PEBBLEGPU_DM_FMM && mode != PEBBLEGPU_DM_FMS) return fail(PEBBLEGPU_E_UNSUPPORTED, "a WFM bank demodulates FMM and FMS only");
         std::lock_guard<std::mutex> g(mu_);
+        touched_ = true;  // the next call joins its two pipelines before the change is applied
         if (int rc = wfmc_.set_stereo(ch, mode == PEBBLEGPU_DM_FMS)) return rc;
         ctl_[ch].mode = mode;
         return 0;
@@ -135,6 +138,7 @@ int Receiver::set_mode(uint32_t ch, int mode)
         return fail(PEBBLEGPU_E_UNSUPPORTED, "demod mode %d is not available in a narrow bank (FMM and FMS need a wfm bank)", mode);
     }
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     if (ctl_[ch].mode != mode) am_list_dirty_ = true;
     ctl_[ch].mode = mode;
     if (!wfm) {  // "Tune only mode": the reference returns before NoiseFilter and AGC (receiver.cpp:968-971): their states stay frozen
@@ -169,6 +173,7 @@ int Receiver::set_squelch(uint32_t ch, double squelch_db)
             if (int rc = enable_smeter(true)) return rc;
         }
         std::lock_guard<std::mutex> g(mu_);
+        touched_ = true;  // the next call joins its two pipelines before the change is applied
         PG_HIP(hipSetDevice(device));
         if (squelch_.empty()) squelch_.assign(C, -120.f);
         if (!d_squelch) {
@@ -185,6 +190,7 @@ int Receiver::set_squelch(uint32_t ch, double squelch_db)
         if (int rc = enable_smeter(true)) return rc;
     }
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     if (squelch_db > -120.0 && !h_gate_) {
         PG_HIP(hipSetDevice(device));
         PG_HIP(hipHostMalloc((void **)&h_gate_, sizeof(float4)));
@@ -196,6 +202,7 @@ int Receiver::set_squelch(uint32_t ch, double squelch_db)
 int Receiver::set_conditioners(uint32_t stream, int flags, double iq_gain, double iq_phase)
 {
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     PG_HIP(hipSetDevice(device));
     return cond_.set(stream, flags, iq_gain, iq_phase);
 }
@@ -204,6 +211,7 @@ int Receiver::set_noise_filter(uint32_t ch, bool on)
 {
     if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the WFM branch has no noise filter step (receiver.cpp:854-901)");
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     PG_HIP(hipSetDevice(device));
     return anf_.set(ch, on);
 }
@@ -213,6 +221,7 @@ int Receiver::set_agc(uint32_t ch, int mode, int threshold)
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the WFM branch has no AGC (receiver.cpp:854-901)");
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     return agc_.set_mode(ch, mode, threshold);
 }
 
@@ -221,6 +230,7 @@ int Receiver::set_bandpass(uint32_t ch, double lo, double hi)
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the WFM branch has no band-pass (receiver.cpp:854-901)");
     std::lock_guard<std::mutex> g(mu_);
+    touched_ = true;  // the next call joins its two pipelines before the change is applied
     ChanCtl &c = ctl_[ch];
     const double flo = (double)(float)lo, fhi = (double)(float)hi;  // setBandPass(float, float), bandpassfilter.cpp:38
     if (c.mode == PEBBLEGPU_DM_AM) {  // Demod::setBandwidth only acts in AM (demod.cpp:230-239)
@@ -239,9 +249,9 @@ int Receiver::set_bandpass(uint32_t ch, double lo, double hi)
     return 0;
 }
 
-int Receiver::apply_controls()
+int Receiver::apply_controls(hipStream_t osc_stream)
 {
-    if (int rc = osc_.upload(stream_)) return rc;
+    if (int rc = osc_.upload(osc_stream)) return rc;
     if (smeter_on && sm_dirty_) {
         // bin indices of fdEstimate (signalstrength.cpp:313-337): integer bin width, truncating conversions, qBound
         std::vector<SmBins> hb(C);
@@ -315,11 +325,21 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // the chain's first kernel needs no LDS -- the transform's workgroups leave none -- and nothing downstream reads the
     // spectrum or a conditioned copy of the input)
     const bool side = with_spectrum && with_chain && !profile_detail && squelch_db_ <= -120.0 && !bank_gate_ && dec_.front_is_lds_free() && !cond_.any && !cond_.dirty;
-    if (chain_end_) {  // the previous call's chain may still be running on its own stream
-        PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
-        chain_end_ = nullptr;
-    }
-    if (int rc = apply_controls()) return rc;
+    // Pipelined calls: the display transforms of successive calls follow one another on the main stream and the chains on the
+    // chain's stream -- neither waits for the other's previous call (they share nothing: the transform carries its previous
+    // amplitudes, the chain its histories and oscillators), so a call's short, LDS-hungry tail kernels run beside the NEXT
+    // call's transform instead of on an idle GPU.  Results are complete after sync() (the contract of include/pebblegpu.h).
+    // Anything else -- a control change to apply, a call of another shape -- first orders the two queues behind each other.
+    const bool plain = side && pipeline_ && !touched_;
+    auto join = [&]() -> int {
+        if (chain_end_) PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
+        if (spec_end_) PG_HIP(hipStreamWaitEvent(chain_stream_, spec_end_, 0));
+        chain_end_ = spec_end_ = nullptr;
+        return 0;
+    };
+    if (!plain) { if (int rc = join()) return rc; }
+    if (int rc = apply_controls(plain ? chain_stream_ : stream_)) return rc;
+    touched_ = false;
     if (int rc = cond_.apply(stream_)) return rc;
     if (raw) {
         // Raw device-format input: when the call's first kernels convert in their own loads (the 8192-bin display transform
@@ -328,6 +348,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         dec_.want_lds_free = side;
         const bool fused = side && S == 1 && spec_.raw_ready() && dec_.raw_ready(osc_);
         if (!fused) {
+            if (plain) { if (int rc = join()) return rc; }  // the staging buffer is shared by successive calls
             if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
             // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
             if (int rc = run_normalize_iq(raw->fmt, raw->order, 1.0, raw->base, (long long)(S * n), d_raw_stage_, stream_, false, raw->scale)) return rc;
@@ -466,7 +487,12 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (int rc = osc_.advance_job(cs, n, &oa)) return rc;
         if (int rc = run_save_tails(cs, jobs, C, &oa)) return rc;
     }
-    if (side) {
+    if (side && pipeline_) {
+        // the call's two pipelines end separately: whoever needs both waits for both (sync(), the next call that is not plain)
+        PG_HIP(hipEventRecord(ev[6], cs));
+        chain_end_ = ev[6];
+        spec_end_ = ev[1];
+    } else if (side) {
         // join: the call has ended once both pipelines have, and it ends on the chain's stream.  That stream is the main stream
         // of the next call (the two swap roles): its first kernel then follows this call's last in queue order, where a wait
         // on an event from the other queue cost ~25 us of idle GPU per call
@@ -497,7 +523,7 @@ int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, ui
 const char *Receiver::kernel_name(int which) const
 {
     switch (which) {
-    case 1: return !bins ? "" : spec_.big ? "k_big_cols + k_big_rows" : spec_.per_q ? "k_spectrum_q128" : bins == 8192 ? "k_spectrum_t128" : bins == 4096 ? "k_spectrum<2>" : "k_spectrum_1to1";
+    case 1: return !bins ? "" : spec_.big ? "k_big_cols + k_big_rows" : spec_.per_q ? "k_spectrum_q128" : bins == 8192 ? (spec_.use_w64 ? "k_spectrum_w64" : "k_spectrum_t128") : bins == 4096 ? "k_spectrum<2>" : "k_spectrum_1to1";
     case 2: return dec_.front_name;
     case 3: return dec_.rest_name;
     case 4: return wfm ? "" : ff_n == 2048 ? "k_fastfir_t128" : "k_fastfir";

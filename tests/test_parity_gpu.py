@@ -412,14 +412,20 @@ def test_config1_variant_8192_fastfir(gpu_lib, oracle_mod):
     assert got == 3
 
 
-def test_config2_wfm_with_spectrum(gpu_lib, oracle_mod):
+@pytest.mark.parametrize("route", ["default", "one-wave transform, pipelined calls"])
+def test_config2_wfm_with_spectrum(gpu_lib, oracle_mod, monkeypatch, route):
     """BASELINE config 2 (the bench workload) at parity size: 20 Msps HackRF-shape int8 IQ, 1 channel, mixer +1 MHz,
     chain hb11x8,hb15,hb23,hb47 -> 312.5 kHz, WFM mono, 8192-bin spectrum on every 2048-sample frame.
     The oracle runs frame size 8192 (>= every stage's taps) because the cascade is frame-invariant
-    (tests/test_oracle_pins.py::test_decimator_is_frame_invariant) and 2048 would hit the reference's fallback."""
+    (tests/test_oracle_pins.py::test_decimator_is_frame_invariant) and 2048 would hit the reference's fallback.
+    Second route: the opt-in kernel on the one-wave transform (fft_w64.h) with calls that do not join their two streams."""
     import pebblesdr_amd as P
     fs, n = 20_000_000, 2048
+    if route != "default":
+        monkeypatch.setenv("PEBBLEGPU_SPECTRUM_W64", "1")
+        monkeypatch.setenv("PEBBLEGPU_PIPELINE", "1")
     rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=4)
+    assert rx.kernel_name(1) == ("k_spectrum_t128" if route == "default" else "k_spectrum_w64")
     assert rx.chain() == [(11, 8), (15, 2), (23, 2), (47, 2)] and rx.D == 64 and rx.info.demod_rate == 312500.0
     rx.set_mixer(0, 1.0e6)
     sf = rx.superframe
@@ -1602,9 +1608,11 @@ def test_squelch_in_a_bank(gpu_lib, oracle_mod):
     assert opened >= 12
 
 
-@pytest.mark.parametrize("fmt,dtype,scale,order", [(0, np.int8, 128.0, 0), (1, np.uint8, 128.0, 1), (2, np.int16, 32768.0, 0), (4, np.int16, 32767.0, 3),
-                                                   (3, np.float32, 1.0, 1)])
-def test_process_raw_converting_in_the_first_loads(gpu_lib, fmt, dtype, scale, order):
+@pytest.mark.parametrize("fmt,dtype,scale,order,w64", [(0, np.int8, 128.0, 0, 0), (1, np.uint8, 128.0, 1, 0), (2, np.int16, 32768.0, 0, 0),
+                                                       (4, np.int16, 32767.0, 3, 0), (3, np.float32, 1.0, 1, 0),
+                                                       (0, np.int8, 128.0, 1, 1), (1, np.uint8, 128.0, 0, 1), (2, np.int16, 32768.0, 2, 1),
+                                                       (4, np.int16, 32767.0, 0, 1), (3, np.float32, 1.0, 0, 1)])
+def test_process_raw_converting_in_the_first_loads(gpu_lib, monkeypatch, fmt, dtype, scale, order, w64):
     """The bench's own shape fed in the device's sample format: at 20 Msps / 8192 bins / one channel the display transform and the
     first decimator stage read the raw pairs themselves (k_spectrum_t128<.., RAW>, k_mix_hb11_lean<RAW>: no float2 copy of the
     stream exists).  Every format and IQ order of normalizeIQ (deviceinterfacebase.cpp:648-838; WAV PCM16: wavfile.cpp:299-300)
@@ -1612,6 +1620,8 @@ def test_process_raw_converting_in_the_first_loads(gpu_lib, fmt, dtype, scale, o
     calls, so the second one's first windows come from the history the first one left."""
     import pebblesdr_amd as P
     fs, bins = 20_000_000, 8192
+    if w64:  # the opt-in display kernel converts in its loads as well (k_spectrum_w64<FMT>)
+        monkeypatch.setenv("PEBBLEGPU_SPECTRUM_W64", "1")
     a = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
     b = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
     for rx in (a, b):
@@ -1638,7 +1648,48 @@ def test_process_raw_converting_in_the_first_loads(gpu_lib, fmt, dtype, scale, o
             buf.free()
         gb, sb = b.process(x[lo:hi])
         if lo:  # (the first call of a fresh receiver sits inside the oscillator's amplitude transient and takes the general route)
-            assert a.kernel_name(2) == "k_mix_hb11_lean" and a.kernel_name(1) == "k_spectrum_t128"
+            assert a.kernel_name(2) == "k_mix_hb11_lean" and a.kernel_name(1) == ("k_spectrum_w64" if w64 else "k_spectrum_t128")
         assert np.abs(ga).max() > 1e-3
         assert np.array_equal(ga, gb)
         assert np.array_equal(sa, sb)
+
+
+def test_pipelined_calls_run_back_to_back_and_match_joined_calls(gpu_lib, monkeypatch):
+    """PEBBLEGPU_PIPELINE=1: successive calls no longer join their two streams -- the display transforms follow one another on
+    one stream, the chains on the other, and a call's tail runs beside the next call's transform.  Five calls queued without
+    a host synchronisation in between, a retune before the fourth (a setter makes the next call join first, so the change
+    lands between the right two calls): audio bit for bit what a receiver that joins every call gives, spectrum of the last
+    call as well (same kernels on both sides)."""
+    import pebblesdr_amd as P
+    fs, bins = 20_000_000, 8192
+    monkeypatch.setenv("PEBBLEGPU_PIPELINE", "1")
+    a = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=2)
+    monkeypatch.delenv("PEBBLEGPU_PIPELINE")
+    b = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=2)
+    for rx in (a, b):
+        rx.set_mixer(0, 1.0e6)
+    n = 2 * a.superframe
+    t = np.arange(5 * n) / fs
+    x = (0.4 * np.exp(1j * (2 * np.pi * 1.0e6 * t + 75.0 * np.sin(2 * np.pi * 1000 * t))) + lcg_noise(5 * n, 9, 1e-2)).astype(np.complex64)
+    bufs = [P.DeviceBuffer.from_array(P.binding.to_f32_iq(x[k * n:(k + 1) * n]), 0) for k in range(5)]
+    try:
+        want_a, want_s = [], []
+        for k in range(5):
+            if k == 3:
+                b.set_mixer(0, 1.2e6)
+            b.process_device(bufs[k].ptr, n)
+            b.synchronize()
+            want_a.append(b.audio().copy()); want_s.append(b.spectrum().copy())
+        for k in range(3):
+            a.process_device(bufs[k].ptr, n)  # no synchronisation between these
+        a.synchronize()
+        assert np.array_equal(a.audio(), want_a[2]) and np.array_equal(a.spectrum(), want_s[2])
+        a.set_mixer(0, 1.2e6)
+        for k in (3, 4):
+            a.process_device(bufs[k].ptr, n)
+        a.synchronize()
+        assert np.abs(a.audio()).max() > 1e-3
+        assert np.array_equal(a.audio(), want_a[4]) and np.array_equal(a.spectrum(), want_s[4])
+    finally:
+        for bf in bufs:
+            bf.free()
