@@ -223,7 +223,7 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
     const pg::Timers &t = h->rx.tm;
     if (t.calls == 0) return fail(PEBBLEGPU_E_INVALID, "no call has been made yet");
     if (last_k == 0) last_k = 1;
-    if (last_k > (uint32_t)pg::Timers::kRing) last_k = pg::Timers::kRing;
+    if (last_k > (uint32_t)pg::Timers::kRing - 1) last_k = pg::Timers::kRing - 1;  // (the oldest slot's start may be an event the newest call has re-recorded)
     if ((uint64_t)last_k > t.calls) last_k = (uint32_t)t.calls;
     static const int a[6] = {0, 0, 1, 2, 3, 4}, b[6] = {6, 1, 2, 3, 4, 5};
     double sum = 0;
@@ -236,10 +236,11 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
         PG_HIP(hipEventSynchronize(ev[6]));
         if (has_mid) PG_HIP(hipEventSynchronize(ev[1]));  // pipelined calls: the transform's stream ends on its own
         if (which == 1 && !has_mid) continue;  // no display transform in that call: 0 ms
-        PG_HIP(hipEventElapsedTime(&one, ev[a[which]], ev[b[which]]));
+        const hipEvent_t start = t.start_ev[(t.calls - 1 - k) % pg::Timers::kRing];
+        PG_HIP(hipEventElapsedTime(&one, a[which] == 0 ? start : ev[a[which]], ev[b[which]]));
         if (which == 0 && has_mid) {  // the call lasted until the later of its two pipelines
             float other = 0;
-            PG_HIP(hipEventElapsedTime(&other, ev[0], ev[1]));
+            PG_HIP(hipEventElapsedTime(&other, start, ev[1]));
             if (other > one) one = other;
         }
         sum += one;

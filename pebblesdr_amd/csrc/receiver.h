@@ -316,6 +316,7 @@ struct SpectrumCore {
 struct Timers {
     static constexpr int kRing = 64;
     hipEvent_t ev[kRing][8] = {};
+    hipEvent_t start_ev[kRing] = {};  // where the call began: its own ev[0], or the previous call's end event when it queued straight behind it
     bool detailed[kRing] = {};   // per-kernel events (2..5) were recorded for that call
     bool has_mid[kRing] = {};    // event 1 (behind the display transform) was recorded: calls without a spectrum skip it unless profiling
     uint64_t calls = 0;
@@ -392,6 +393,7 @@ private:
     // No events of its own: the chain stream waits for the call's start event, the call's end event is recorded on the chain
     // stream once it has also seen the transform's end event, and whatever next touches the main stream (the next call, a
     // synchronise) first waits for that end event.  Every event record costs the stream ~5 us, so none is spent on the fork/join.
+    hipEvent_t last_end_ = nullptr;   // the previous call's end event, recorded on what is now the main stream (a call queued behind a busy stream starts there)
     hipEvent_t spec_end_ = nullptr;   // pipelined calls: the last display transform queued on the main stream (for the chain's stream to wait on at a join)
     bool pipeline_ = false;           // successive side-by-side calls overlap (PEBBLEGPU_PIPELINE=1 when the receiver is created)
     bool touched_ = true;             // a setter ran since the last call

@@ -330,6 +330,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // amplitudes, the chain its histories and oscillators), so a call's short, LDS-hungry tail kernels run beside the NEXT
     // call's transform instead of on an idle GPU.  Results are complete after sync() (the contract of include/pebblegpu.h).
     // Anything else -- a control change to apply, a call of another shape -- first orders the two queues behind each other.
+    const bool was_touched = touched_;
     const bool plain = side && pipeline_ && !touched_;
     auto join = [&]() -> int {
         if (chain_end_) PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
@@ -341,12 +342,14 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (int rc = apply_controls(plain ? chain_stream_ : stream_)) return rc;
     touched_ = false;
     if (int rc = cond_.apply(stream_)) return rc;
+    bool staged = false;  // a conversion pass was queued in front of the call
     if (raw) {
         // Raw device-format input: when the call's first kernels convert in their own loads (the 8192-bin display transform
         // and the one-channel first stage beside it) there is no float2 copy of the stream at all; otherwise normalizeIQ runs
         // as its own pass into a staging buffer and the call goes on from there.
         dec_.want_lds_free = side;
         const bool fused = side && S == 1 && spec_.raw_ready() && dec_.raw_ready(osc_);
+        staged = !fused;
         if (!fused) {
             if (plain) { if (int rc = join()) return rc; }  // the staging buffer is shared by successive calls
             if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
@@ -360,11 +363,20 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // DCRemoval, IQBalance, NoiseBlanker 1/2 on the raw streams, ahead of the spectrum and the mixer (receiver.cpp:814-823)
     if (int rc = cond_.run(stream_, d_iq, in_pitch, (long long)n, &d_iq, &in_pitch)) return rc;
     hipEvent_t *ev = tm.slot();
+    const int slot = (int)(tm.calls % Timers::kRing);
     tm.calls++;
-    PG_HIP(hipEventRecord(ev[0], stream_));
+    // Every event record is a packet of its own in the queue (~6 us of idle GPU between two kernels).  A side-by-side call queued
+    // straight behind a still-busy stream starts exactly where the previous call ended: it takes that call's end event as its
+    // start instead of recording one.
+    hipEvent_t start = ev[0];
+    static const bool lean_events = [] { const char *e = getenv("PEBBLEGPU_EVENTS"); return !(e && e[0] == 'f'); }();  // =full: every call records its own start, joins at its end (A/B)
+    if (lean_events && side && !pipeline_ && !was_touched && !staged && last_end_ && hipStreamQuery(stream_) == hipErrorNotReady) start = last_end_;
+    else PG_HIP(hipEventRecord(ev[0], stream_));
+    tm.start_ev[slot] = start;
+    last_end_ = nullptr;
     hipStream_t cs = side ? chain_stream_ : stream_;
     if (side) {
-        PG_HIP(hipStreamWaitEvent(chain_stream_, ev[0], 0));  // fork: the input is ready where the call's start event is
+        PG_HIP(hipStreamWaitEvent(chain_stream_, start, 0));  // fork: the input is ready where the call starts
     }
     // From here on a failing step leaves kernels queued (on the chain stream too) and histories half advanced: whatever the
     // exit, join the two streams so later work is ordered behind what was queued, and refuse further calls on the handle.
@@ -393,6 +405,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (!with_chain) {
         if (profile_detail) for (int i = 2; i <= 5; i++) PG_HIP(hipEventRecord(ev[i], stream_));
         PG_HIP(hipEventRecord(ev[6], stream_));
+        last_end_ = ev[6];
         guard.armed = false;
         return 0;
     }
@@ -499,8 +512,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
         PG_HIP(hipEventRecord(ev[6], cs));
         std::swap(stream_, chain_stream_);
+        last_end_ = ev[6];
     } else {
         PG_HIP(hipEventRecord(ev[6], stream_));
+        last_end_ = ev[6];
     }
     osc_.advance(n);
     guard.armed = false;
