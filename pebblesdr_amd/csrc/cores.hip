@@ -428,6 +428,11 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
     for (int i = 0; i < 2; i++) {
         PG_HIP(hipMalloc((void **)&d_hist_mixed[i], sizeof(float2) * kMaxTaps * C));
         PG_HIP(hipMemset(d_hist_mixed[i], 0, sizeof(float2) * kMaxTaps * C));
+        if (C == 1) {
+            PG_HIP(hipMalloc((void **)&d_xtail_w[i], sizeof(float2) * 2048));
+            PG_HIP(hipMemset(d_xtail_w[i], 0, sizeof(float2) * 2048));
+        }
+
     }
     return 0;
 }
@@ -449,7 +454,98 @@ void DecimCore::release()
     for (int i = 0; i < 2; i++) {
         if (d_hist_mixed[i]) (void)hipFree(d_hist_mixed[i]);
         d_hist_mixed[i] = nullptr;
+        if (d_xtail_w[i]) (void)hipFree(d_xtail_w[i]);
+        d_xtail_w[i] = nullptr;
     }
+    if (d_r0tab) (void)hipFree(d_r0tab);
+    d_r0tab = nullptr;
+    if (d_ph_scratch) (void)hipFree(d_ph_scratch);
+    d_ph_scratch = nullptr;
+    ph_cap = 0;
+}
+int DecimCore::set_fuse_window(const float *d_window, const std::vector<float> &w)
+{
+    fuse_window = nullptr;
+    if (C != 1 || w.size() != 2048 || !bank_front) return 0;
+    static const int kD[7] = {0, 2, 4, 5, 6, 8, 10};
+    std::vector<float> t(7 * 256);
+    for (int i = 0; i < 7; i++)
+        for (int jf = 0; jf < 256; jf++) t[256 * i + jf] = bank_taps.h[kD[i]] / w[(8 * jf - 10 + kD[i]) & 2047];
+    if (!d_r0tab) PG_HIP(hipMalloc((void **)&d_r0tab, sizeof(float) * t.size()));
+    PG_HIP(hipMemcpy(d_r0tab, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
+    fuse_window = d_window;
+    return 0;
+}
+bool DecimCore::shape_for_spectrum() const
+{
+    return C == 1 && bank_front && !fused_all && !fused_front && !wide && first.stride == 8 && casc.nst == 3 && casc.stride[0] == 2 && casc.stride[1] == 2 &&
+           casc.stride[2] == 2 && casc.ntaps[0] == 15 && casc.ntaps[1] == 23 && casc.ntaps[2] == 47 && buf0.hist <= 256 && d_xtail_w[0] != nullptr && d_r0tab != nullptr;
+}
+int DecimCore::fill_dec_fuse(DecFuse *df, const OscBank &osc, long long n)
+{
+    if (n <= 0 || n % 2048 != 0) return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a whole number of 2048-sample frames", n);
+    len0 = n / first.stride;
+    len_out = n / (long long)chain.total;
+    if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+    memset(df, 0, sizeof(*df));
+    df->y = fin.data();
+    df->y0_tail = buf0.data() + (len0 - 256);
+    df->xtail = d_xtail_w[xtail_parity];
+    df->xtail_next = d_xtail_w[xtail_parity ^ 1];
+    const ChanOsc &o = osc.h_osc[0];
+    df->phase0 = osc.inline_dyn.use ? osc.inline_dyn.d[0].phase0 : osc.ctl[0].phase0;
+    df->inc = o.inc;
+    df->a_inf = osc.a_inf;
+    df->gain0 = first.gain;
+    df->gain_last = casc.gain;
+    df->mix_on = (int)o.mix_on;
+    for (int p = 0; p < 11; p++) df->step[p] = o.step[p];
+    {
+        double ph = 2048.0 * o.inc;
+        ph -= std::floor(ph);
+        df->wfr = make_float2((float)std::cos(design::kTwoPi * ph), (float)std::sin(design::kTwoPi * ph));
+    }
+    df->r0tab = d_r0tab;
+    {
+        // one 2 KiB row per frame chain of the transform's launch (chains of at most 32 frames, at least 512 of them)
+        const size_t need = (size_t)(n / 2048 + 1024) * 256;
+        if (need > ph_cap) {
+            if (d_ph_scratch) (void)hipFree(d_ph_scratch);
+            d_ph_scratch = nullptr;
+            ph_cap = 0;
+            PG_HIP(hipMalloc((void **)&d_ph_scratch, sizeof(float2) * need));
+            ph_cap = need;
+        }
+        df->ph_scratch = d_ph_scratch;
+    }
+    return 0;
+}
+// the call's last 2048 samples, windowed: the look-back of a later call whose decimator runs inside the display transform
+static __global__ __launch_bounds__(256) void k_window_tail(const float2 *__restrict__ in, long long n, const float *__restrict__ window, float2 *__restrict__ out,
+                                                            RawSrc raw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const long long src = n - 2048 + i;
+    const float2 v = raw.base ? raw_load(raw, src) : in[src];
+    out[i] = cscale(v, window[i]);
+}
+int DecimCore::run_beside_spectrum(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc, const RawSrc *raw)
+{
+    // (fill_dec_fuse has set the lengths.)  The general kernels keep the mixed samples of the call's end as their history: left by the
+    // same two-workgroup launch that serves k_mix_hb11_lean, so the next call may take either route
+    const int R = 8;
+    const long long j_first = (10 + first.stride - 1) / first.stride;
+    const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
+    launch(raw ? k_mix_hb11_bank<false, false, true> : k_mix_hb11_bank<false, false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch,
+           (int)shared_input, buf0.data(), buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1],
+           (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first, rs);
+    PG_HIP(hipGetLastError());
+    hist_parity ^= 1;
+    xtail_parity ^= 1;  // the transform's last workgroup writes the next call's look-back
+    last_fused = false;
+    front_name = "k_spectrum_t128 (decimator inside)";
+    rest_name = "";
+    return 0;
 }
 int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
                    hipEvent_t after_first, const RawSrc *raw)
@@ -567,6 +663,10 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     PG_HIP(hipGetLastError());
     if (fused_all && shared_input)  // the next call may take the fused route: it wants this call's raw tail (hist_parity already flipped)
         PG_HIP(hipMemcpyAsync(d_xhist[hist_parity], d_in + (n - 16), sizeof(float2) * 16, hipMemcpyDeviceToDevice, s));
+    if (fuse_window && n >= 2048 && shape_for_spectrum()) {  // the next call's decimator may run inside the display transform
+        launch(k_window_tail, dim3(8), dim3(256), s, d_in, n, fuse_window, d_xtail_w[xtail_parity ^ 1], raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0});
+        xtail_parity ^= 1;
+    }
     return 0;
 }
 void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
@@ -1359,6 +1459,7 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     for (uint32_t i = 0; i < nf; i++) wf[i] = (float)w[i];
     PG_HIP(hipMalloc((void **)&d_window, sizeof(float) * nf));
     PG_HIP(hipMemcpy(d_window, wf.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+    h_window = wf;
     // btab[q][m] = exp(-2*pi*i*(64*m*q)/bins): the wave-uniform factor of the pruned-FFT pre-twiddle W_bins^{n q},
     // n = lane + 64 m (the per-lane factor W_bins^{lane q} is computed in the kernel)
     const uint32_t zp = bins / nf;
@@ -1412,8 +1513,9 @@ void SpectrumCore::release()
     d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr; d_btab128 = d_tw128 = nullptr;
     y_cap = 0;
 }
-int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out, const RawSrc *raw)
+int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out, const RawSrc *raw, const DecFuse *df)
 {
+    if (df && !dec_ready()) return fail(PEBBLEGPU_E_INVALID, "the decimator was handed to a display transform that cannot run it");
     if (raw && !raw_ready()) return fail(PEBBLEGPU_E_INVALID, "raw-format input reached a spectrum kernel that has no converting loads");
     SpectrumParams sp;
     sp.in_pitch = in_pitch;
@@ -1506,10 +1608,25 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
         const float *pin = d_prev[parity];
         float *pout = d_prev[parity ^ 1];
-        if (raw) {  // raw-format frames take the two-chain kernel (one instantiation per sample format)
+        DecFuse none;
+        memset(&none, 0, sizeof(none));
+        const DecFuse &dfv = df ? *df : none;
+        if (df) {  // the one-channel decimator rides in the transform's workgroups (two chains per workgroup, every sample format)
+            const dim3 grid(cdiv(cdiv(F, G8), 2), S), block(1024);
+            const int st = stagger > 0 ? stagger : 3;
+            auto go = [&](auto kern) { launch(kern, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, st, rs, dfv); };
+            switch (raw ? raw->fmt : -1) {
+            case -1: go(k_spectrum_t128<2, -1, true>); break;
+            case 0: go(k_spectrum_t128<2, 0, true>); break;
+            case 1: go(k_spectrum_t128<2, 1, true>); break;
+            case 2: go(k_spectrum_t128<2, 2, true>); break;
+            case 3: go(k_spectrum_t128<2, 3, true>); break;
+            default: go(k_spectrum_t128<2, 4, true>); break;
+            }
+        } else if (raw) {  // raw-format frames take the two-chain kernel (one instantiation per sample format)
             const dim3 grid(cdiv(cdiv(F, G8), 2), S), block(1024);
             const int st = stagger > 0 ? stagger : 7;
-            auto go = [&](auto kern) { launch(kern, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, st, rs); };
+            auto go = [&](auto kern) { launch(kern, grid, block, s, d_in, d_out, (const float *)d_window, (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, st, rs, dfv); };
             switch (raw->fmt) {
             case 0: go(k_spectrum_t128<2, 0>); break;
             case 1: go(k_spectrum_t128<2, 1>); break;
@@ -1519,10 +1636,10 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
             }
         } else if (stagger > 0)  // two chains per 1024-item workgroup, the second `stagger` barrier intervals behind the first
             launch(k_spectrum_t128<2, -1>, dim3(cdiv(cdiv(F, G8), 2), S), dim3(1024), s, d_in, d_out, (const float *)d_window,
-                   (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, stagger, rs);
+                   (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, stagger, rs, dfv);
         else
             launch_lds(k_spectrum_t128<1, -1>, dim3(cdiv(F, G8), S), dim3(512), (size_t)pad_lds, s, d_in, d_out, (const float *)d_window,
-                       (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, 0, rs);
+                       (const float2 *)d_btab128, (const float2 *)d_tw128, pin, pout, sp, 0, rs, dfv);
         parity ^= 1;
         PG_HIP(hipGetLastError());
         return 0;

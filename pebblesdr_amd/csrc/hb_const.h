@@ -1,0 +1,11 @@
+// hb_const.h -- the halfband coefficient tables (generated data, hb_taps.inc) as compile-time constants: with a constant design and
+// tap index the load folds to a literal, so the coefficients of a chain need no registers and no loads.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pg {
+namespace hbc {
+#include "hb_taps.inc"
+}
+template <int T> __device__ __forceinline__ float hb_tap(int p) { return (float)hbc::pebble_hb_designs[(T - 7) / 4].h[p]; }
+}  // namespace pg

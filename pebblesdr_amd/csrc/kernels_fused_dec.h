@@ -51,15 +51,11 @@
 #pragma once
 #include "kernels_frontend.h"
 #include "params.h"
+#include "hb_const.h"
 
 namespace pg {
 
-// The halfband coefficient tables (generated data, hb_taps.inc) as compile-time constants: with a constant design and tap index
-// the load folds to a literal, so the ~45 coefficients of a chain need no registers (held in scalar registers they spilled).
-namespace hbc {
-#include "hb_taps.inc"
-}
-template <int T> __device__ __forceinline__ float hb_tap(int p) { return (float)hbc::pebble_hb_designs[(T - 7) / 4].h[p]; }
+// (hb_tap<T>(p): the halfband coefficients as literals, hb_const.h -- held in scalar registers the ~45 of a chain spilled)
 
 struct FusedDecParams {
     long long n_out;          // final outputs per channel in this call

@@ -34,6 +34,7 @@
 #include "fft_lds.h"
 #include "fft_t128.h"
 #include "fft_w64.h"
+#include "hb_const.h"
 #include "params.h"
 
 namespace pg {
@@ -199,20 +200,34 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
 // FMT >= 0: the frames are read in the device's own sample format (RawSrc, pebblegpu_iq_format FMT) and converted in the load --
 // normalizeIQ without a float2 copy of the stream (2 instead of 8 bytes per sample from HBM for HackRF / RTL int8 pairs).  A
 // work-item then takes four CONSECUTIVE samples (one 8- or 16-byte load) instead of four samples 512 apart.
-template <int HALVES, int FMT>
+// DEC: the workgroup also runs the one-channel mixer + decimator (hb11 x 8, hb15, hb23, hb47) over the frames it parks in LDS for
+// the transforms -- the stream crosses HBM once instead of twice and nothing is written at the intermediate rates.  A half's chain
+// of frames is a chain for the decimator as well: the frame in front of it (loaded anyway for the previous amplitudes; for the call's
+// first chain the previous call's last frame, DecFuse::xtail) is the cascade's whole look-back (1946 samples).  The stages run in the
+// barrier intervals the transform already has, each on other waves: first stage from the parked (windowed) frame with taps h[d] / w[n]
+// before barrier A, hb15 / hb23 / hb47 after the transform's first three exchanges barriers, through three small LDS arrays whose
+// heads hold the previous frame's last T - 1 outputs.
+struct DecLds {
+    float2 z0[14 + 256], z1[22 + 128], z2[2][46 + 64], xt[2][10];  // (z2 twice: hb47 runs a frame behind hb23, which is writing the next one)
+};
+
+template <int HALVES, int FMT, bool DEC = false>
 static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
                                                                  const float *__restrict__ window, const float2 *__restrict__ btab128,
                                                                  const float2 *__restrict__ tw128, const float *__restrict__ prev_in,
-                                                                 float *__restrict__ prev_out, SpectrumParams sp, int shift, RawSrc raw)
+                                                                 float *__restrict__ prev_out, SpectrumParams sp, int shift, RawSrc raw,
+                                                                 DecFuse df)
 {
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP, XOFF = NF / 2;
     constexpr int REGION = FftLds<NF>::kSlots;
     constexpr bool RAW = FMT >= 0;
     __shared__ float2 lds_all[HALVES][4][REGION];
     __shared__ float2 tw_lds[kTw128Count];
+    __shared__ DecLds dec_all[DEC ? HALVES : 1];
     const int tid = threadIdx.x & 511, lane = tid & 63;
     const int half = HALVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0;
     float2 (*lds)[REGION] = lds_all[half];
+    DecLds &dl = dec_all[DEC ? half : 0];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wave >> 1, s = blockIdx.y;
     const int G = sp.frames_per_group;
@@ -231,6 +246,19 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float pa[E];
     float2 xn[4];
+    constexpr int kD[7] = {0, 2, 4, 5, 6, 8, 10};  // the hb11's non-zero taps (DEC)
+    if (DEC) {
+        for (int i = tid; i < (int)(sizeof(DecLds) / sizeof(float2)); i += 512) reinterpret_cast<float2 *>(&dl)[i] = make_float2(0.f, 0.f);
+    }
+    // the first stage's taps (against windowed samples) and oscillator for the coming frame: requested one barrier interval ahead
+    float r0n[7];
+    float2 phn = make_float2(0.f, 0.f);
+    auto dec_prefetch = [&](int td2) {  // (every work-item: a conditional request would keep the old values alive through the transform)
+#pragma unroll
+        for (int i = 0; i < 7; i++) r0n[i] = df.r0tab[256 * i + (td2 & 255)];
+        phn = df.ph_scratch[((long long)blockIdx.x * HALVES + half) * 256 + (td2 & 255)];
+    };
+    if (DEC) dec_prefetch(tid);
     auto park = [&](int tt) {  // sample n = tt + 512 i goes to region i, slot XOFF + tt (RAW: n = 4 tt + i: region tt / 128, four adjacent slots)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -240,7 +268,11 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     };
     {
         const long long ff = f0 > 0 ? f0 - 1 : 0;
-        if (ff < sp.n_frames) {
+        if (DEC && f0 == 0) {
+            // the call's first chain: the frame in front of the call, kept windowed by the previous call's last workgroup
+#pragma unroll
+            for (int i = 0; i < 4; i++) lds[i][XOFF + tid] = df.xtail[tid + 512 * i];
+        } else if (ff < sp.n_frames) {
             if (RAW) {
                 raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + ff * NF + 4 * tid, xn);
             } else {
@@ -260,7 +292,8 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         int t = t0, td = tid;
         opaque(t);
         opaque(td);
-        const bool fetch = it + 1 < G && f + 1 < sp.n_frames && f >= 0;
+        // (DEC: the call's first chain starts on the frame in front of the call, so its frame 0 is fetched like any other)
+        const bool fetch = it + 1 < G && f + 1 < sp.n_frames && (f >= 0 || DEC);
         if (fetch) {
             if (RAW) {
                 raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + (f + 1) * NF + 4 * td, xn);
@@ -279,6 +312,80 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
                 v[m] = cmul(bq[m], cmul(tw_lane, xv));
             }
         }
+        const bool dec_run = DEC && live;          // (f == -1 included: the look-back frame)
+        const bool dec_emit = dec_run && it >= 0;  // outputs of the chain's own frames leave the kernel
+        const int par = (int)(f & 1);
+        if (dec_run) {
+            if (td < 256) {
+                // first stage: y0[jf] = ph * sum_d (h[d] step[d]) x[8 jf - 10 + d], the samples read windowed and un-windowed by the tap
+                // (taps and oscillator come from memory every frame: nothing of the decimator is held in registers through the transform)
+                float2 ph = make_float2(df.gain0, 0.f);
+                if (df.mix_on) {
+                    // (exact every eighth frame, one rotation per frame in between; carried in memory, not in registers)
+                    ph = ((it + 1) & 7) == 0 ? cscale(cis_cycles(df.phase0 + (double)((long long)NF * f + 8 * td - 9) * df.inc), df.a_inf * df.gain0) : cmul(df.wfr, phn);
+                    df.ph_scratch[((long long)blockIdx.x * HALVES + half) * 256 + td] = ph;
+                }
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    const int n = 8 * td - 10 + kD[i];
+                    const float2 xs = n >= 0 ? lds[n >> 9][XOFF + (n & 511)] : dl.xt[par ^ 1][n + 10];
+                    const float2 xr = cscale(xs, r0n[i]);
+                    acc = (i == 0 || !df.mix_on) ? cadd(acc, xr) : cadd(acc, cmul(df.step[kD[i]], xr));
+                }
+                const float2 y0 = cmul(ph, acc);
+                dl.z0[14 + td] = y0;
+                if (dec_emit && f == sp.n_frames - 1) df.y0_tail[td] = y0;
+            } else if (td < 266) {
+                const int n = NF - 10 + (td - 256);
+                dl.xt[par][td - 256] = lds[n >> 9][XOFF + (n & 511)];
+            }
+        }
+        // The decimator's later stages in the transform's barrier intervals, each on waves of its own.  Interval 1: hb15 of this frame
+        // (waves 4, 5) and hb47 of the PREVIOUS frame (wave 7: its input was finished by hb23 an interval later, last frame);
+        // interval 2: hb23 (wave 6) and the first array's head for the next frame; interval 3: the second array's head.
+        auto hb47 = [&](long long fr, bool emit) {  // 32 outputs of frame fr, the 24 + 1 taps of each split over two lanes 32 apart
+            // (the filter is symmetric: the upper lane walks its 12 taps 46, 44 .. 24 with the lower lane's coefficients 0, 2 .. 22 -- literals)
+            const int m = (td - 448) & 31, part = (td - 448) >> 5;
+            const float2 *z = dl.z2[(int)(fr & 1)];
+            const float2 *w = z + 2 * m + 46 * part;
+            const int sg = 1 - 2 * part;
+            float2 acc = cscale(z[2 * m + 23], part ? 0.f : hb_tap<47>(23));  // the centre with the lower half
+#pragma unroll
+            for (int p = 0; p < 24; p += 2) acc = cadd(acc, cscale(w[sg * p], hb_tap<47>(p)));
+            acc.x += __shfl_down(acc.x, 32);
+            acc.y += __shfl_down(acc.y, 32);
+            if (emit && part == 0) df.y[32 * fr + m] = cscale(acc, df.gain_last);
+        };
+        auto dec_slot = [&](int k) {
+            if (k == 1) {
+                if (dec_run && td >= 256 && td < 384) {  // hb15 over z0
+                    const int m = td - 256;
+                    const float2 *w = dl.z0 + 2 * m;
+                    float2 acc = cscale(w[7], hb_tap<15>(7));
+#pragma unroll
+                    for (int p = 0; p < 15; p += 2) acc = cadd(acc, cscale(w[p], hb_tap<15>(p)));
+                    dl.z1[22 + m] = acc;
+                }
+                // (frame f - 1 went through hb23 an iteration ago; it >= 1: it is one of this chain's own frames)
+                if (DEC && td >= 448 && it >= 1 && f - 1 < sp.n_frames) hb47(f - 1, true);
+            } else if (k == 2) {
+                if (!dec_run) return;
+                if (td >= 384 && td < 448) {  // hb23 over z1, into this frame's z2 and (its last 46) the head of the next frame's
+                    const int m = td - 384;
+                    const float2 *w = dl.z1 + 2 * m;
+                    float2 acc = cscale(w[11], hb_tap<23>(11));
+#pragma unroll
+                    for (int p = 0; p < 23; p += 2) acc = cadd(acc, cscale(w[p], hb_tap<23>(p)));
+                    dl.z2[par][46 + m] = acc;
+                    if (m >= 18) dl.z2[par ^ 1][m - 18] = acc;
+                } else if (td >= 448 && td < 462) {
+                    dl.z0[td - 448] = dl.z0[256 + td - 448];  // its head for the next frame
+                }
+            } else if (k == 3) {
+                if (dec_run && td >= 384 && td < 406) dl.z1[td - 384] = dl.z1[128 + td - 384];  // its head for the next frame
+            }
+        };
         __syncthreads();  // A
         if (live && f < 0) {
             const float *pp = prev_in + (long long)s * BINS + ZP * t + q;
@@ -287,7 +394,11 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         }
         // every work-item of the workgroup takes the same path below (xform is uniform): the barriers inside match
         if (xform) {
-            fft2048_t128(v, my, tw_lds, t, [] { __syncthreads(); });
+            int slot = 0;
+            fft2048_t128(v, my, tw_lds, t, [&] {
+                __syncthreads();
+                if (DEC) dec_slot(++slot);
+            });
             float *st = stage + t;
             float mag[E];
 #pragma unroll
@@ -309,12 +420,24 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
                 for (int m = 0; m < E; m++) pp[ZP * 128 * m] = pa[m];
             }
-        } else if (HALVES > 1) {  // the halves share every barrier: an iteration without a transform still passes its four
+        } else if (HALVES > 1 || DEC) {  // the halves share every barrier: an iteration without a transform still passes its four
 #pragma unroll
-            for (int i = 0; i < 4; i++) __syncthreads();
+            for (int i = 0; i < 4; i++) {
+                __syncthreads();
+                if (DEC) dec_slot(i + 1);
+            }
         }
         __syncthreads();  // B
+        if (DEC) dec_prefetch(td);
         if (fetch) park(td);
+        if (DEC && fetch && f + 1 == sp.n_frames - 1) {
+            // the call's last frame, as parked: the next call's look-back (its samples are this work-item's own four)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int n = RAW ? 4 * td + i : td + 512 * i;
+                df.xtail_next[n] = cscale(xn[i], win[i]);
+            }
+        }
         if (it >= 0 && live) {
             const float *sp0 = reinterpret_cast<const float *>(lds[0]) + td;
             float *yf = y + f * (long long)BINS;
@@ -331,6 +454,21 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
             }
         }
         __syncthreads();  // C
+    }
+    if (DEC) {  // hb47 of the chain's last frame (its input complete since the last iteration's second interval, several barriers ago)
+        const long long fl = f0 + G - 1;
+        if (tid >= 448 && fl < sp.n_frames) {
+            const int m = (tid - 448) & 31, part = (tid - 448) >> 5;
+            const float2 *z = dl.z2[(int)(fl & 1)];
+            const float2 *w = z + 2 * m + 46 * part;
+            const int sg = 1 - 2 * part;
+            float2 acc = cscale(z[2 * m + 23], part ? 0.f : hb_tap<47>(23));
+#pragma unroll
+            for (int p = 0; p < 24; p += 2) acc = cadd(acc, cscale(w[sg * p], hb_tap<47>(p)));
+            acc.x += __shfl_down(acc.x, 32);
+            acc.y += __shfl_down(acc.y, 32);
+            if (part == 0) df.y[32 * fl + m] = cscale(acc, df.gain_last);
+        }
     }
     if (HALVES > 1 && half == 0)
         for (int i = 0; i < shift; i++) __syncthreads();

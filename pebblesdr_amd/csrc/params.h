@@ -127,7 +127,7 @@ __device__ __forceinline__ float2 raw_load(const RawSrc &r, long long i)
     }
     a *= r.scale;
     b *= r.scale;
-    return r.order == 0 ? make_float2(a, b) : r.order == 1 ? make_float2(b, a) : r.order == 2 ? make_float2(a, a) : make_float2(b, b);
+    return make_float2((r.order & 1) == 0 ? a : b, (r.order == 1 || r.order == 2) ? a : b);
 }
 
 // four consecutive samples i .. i + 3 (i a multiple of 4) in one or two wide loads: 8 bytes for the int8 formats, 16 for int16, 32 for float
@@ -155,7 +155,7 @@ __device__ __forceinline__ void raw_load4(const RawSrc &r, long long i, float2 (
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float a = v[2 * k] * r.scale, b = v[2 * k + 1] * r.scale;
-        o[k] = r.order == 0 ? make_float2(a, b) : r.order == 1 ? make_float2(b, a) : r.order == 2 ? make_float2(a, a) : make_float2(b, b);
+        o[k] = make_float2((r.order & 1) == 0 ? a : b, (r.order == 1 || r.order == 2) ? a : b);
     }
 }
 
@@ -186,7 +186,7 @@ __device__ __forceinline__ void raw_load4_even(const RawSrc &r, long long i, flo
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float a = v[2 * k] * r.scale, b = v[2 * k + 1] * r.scale;
-        o[k] = r.order == 0 ? make_float2(a, b) : r.order == 1 ? make_float2(b, a) : r.order == 2 ? make_float2(a, a) : make_float2(b, b);
+        o[k] = make_float2((r.order & 1) == 0 ? a : b, (r.order == 1 || r.order == 2) ? a : b);
     }
 }
 
@@ -201,6 +201,24 @@ struct Gate {
 
 // fdEstimate's bin windows for one channel: noise [nlo, nhi] around the band-pass [lo, hi]; stream = which spectrum it reads
 struct SmBins { int nlo, lo, hi, nhi, bp_bins, stream, pad_[2]; };
+
+// k_spectrum_t128<.., DEC = true>: the one-channel mixer + decimator hb11 x 8, hb15, hb23, hb47 (20 Msps -> 312.5 kHz; the halfbands'
+// coefficients are literals of the kernel, hb_const.h) computed by the
+// display transform's workgroups from the frames they hold in LDS anyway -- the stream crosses HBM once instead of twice, and no
+// first-stage buffer is written or read (kernels_spectrum.h)
+struct DecFuse {
+    float2 *y;               // final outputs, 32 per frame: y[32 f + i]
+    float2 *y0_tail;         // the call's last 256 first-stage outputs (for a later call that takes the general kernels)
+    const float2 *xtail;     // the WINDOWED frame in front of the call (the previous call's last frame; zeros at the very start)
+    float2 *xtail_next;      // this call's last frame, windowed: the next call's xtail
+    double phase0, inc;      // oscillator at input sample n of the call: a_inf e^{j 2 pi (phase0 + (n + 1) inc)}
+    float a_inf, gain0, gain_last;
+    int mix_on;
+    float2 step[11];         // e^{j 2 pi d inc}
+    float2 wfr;              // e^{j 2 pi 2048 inc}: an output's oscillator from one frame to the next
+    float2 *ph_scratch;      // [chains][256]: the first stage's oscillator per output, carried from frame to frame of a chain (L2-resident)
+    const float *r0tab;      // [7][256]: h0[d] / w[8 jf - 10 + d] for the seven non-zero taps d = 0 2 4 5 6 8 10 (taps against WINDOWED samples)
+};
 
 struct SpectrumParams {
     long long in_pitch;      // samples between streams

@@ -111,6 +111,23 @@ struct DecimCore {
     const char *front_name = "";     // the kernel the last run() used for the mixer + first stage (bench / profiling labels)
     const char *rest_name = "";      // ... and for the remaining stages
     float2 *d_hist_mixed[2] = {nullptr, nullptr};  // [C][kMaxTaps]: mixed-sample history of stage 0 (read one, write the other)
+    // One channel through hb11 x 8, hb15, hb23, hb47 beside an 8192-bin display transform: k_spectrum_t128<.., DEC> computes the whole
+    // decimator from the frames it holds in LDS (DecFuse, kernels_spectrum.h).  Its look-back is the previous call's last frame, kept
+    // WINDOWED (the transform's workgroups park windowed frames): written by that kernel, or by k_window_tail behind a call that took
+    // the general kernels, so either route can follow the other.
+    float2 *d_xtail_w[2] = {nullptr, nullptr};     // [2048] ping-pong
+    int xtail_parity = 0;
+    const float *fuse_window = nullptr;            // the display transform's window (set by the owner; nullptr: never fused)
+    float *d_r0tab = nullptr;                      // [7][256] first-stage taps over that window (DecFuse::r0tab)
+    float2 *d_ph_scratch = nullptr;                // DecFuse::ph_scratch
+    size_t ph_cap = 0;
+    int set_fuse_window(const float *d_window, const std::vector<float> &w);  // the owner's display transform uses this window
+    bool shape_for_spectrum() const;               // the chain is the one the kernel is built for
+    bool spectrum_can_run(const OscBank &osc) const { return shape_for_spectrum() && fuse_window && want_lds_free && !osc.any_transient(); }
+    // fills the kernel's parameter block for a call of n samples (before the transform is launched)
+    int fill_dec_fuse(DecFuse *df, const OscBank &osc, long long n);
+    // what is left for the chain's stream in such a call: the mixed-sample history for a later general call (two workgroups)
+    int run_beside_spectrum(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc, const RawSrc *raw);
     int hist_parity = 0;
     // last_hist: head-room of the final buffer (what the consumer looks back at); last_gain: folded into the final stage
     int init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain);
@@ -296,6 +313,7 @@ struct SpectrumCore {
     float2 *d_btab = nullptr, *d_tw_nf = nullptr;  // btab: [bins/nf][32] wave-uniform pre-twiddle factors
     float2 *d_btab128 = nullptr, *d_tw128 = nullptr;  // the same for the two-wave transform (fft_t128.h), 8192 bins
     float2 *d_ftab = nullptr;         // [bins/nf][nf] window[n] * W_bins^{n q}: the one factor per point of k_spectrum_q128
+    std::vector<float> h_window;      // host copy of the window (the decimator's taps against windowed samples)
     bool use_w64 = false;             // 8192 bins on k_spectrum_w64 (PEBBLEGPU_SPECTRUM_W64=1 when the core is created)
     int stagger = 0, pad_lds = 0;     // k_spectrum_t128: barrier intervals between the two halves of a 1024-item workgroup (0: 512-item workgroups)
     bool per_q = false;               // k_spectrum_q128 (one transform per 128-item workgroup) instead of the shared-frame kernels
@@ -307,7 +325,8 @@ struct SpectrumCore {
     int parity = 0;
     int init(uint32_t streams, uint32_t frame, uint32_t fft_size);
     void release();
-    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, const RawSrc *raw = nullptr);
+    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, const RawSrc *raw = nullptr, const DecFuse *df = nullptr);
+    bool dec_ready() const { return !big && !per_q && bins == 8192 && !use_w64; }  // k_spectrum_t128<.., DEC> exists for this plan
     bool raw_ready() const { return !big && !per_q && bins == 8192; }  // k_spectrum_t128 converts in its loads
 };
 
@@ -397,6 +416,7 @@ private:
     hipEvent_t spec_end_ = nullptr;   // pipelined calls: the last display transform queued on the main stream (for the chain's stream to wait on at a join)
     bool pipeline_ = false;           // successive side-by-side calls overlap (PEBBLEGPU_PIPELINE=1 when the receiver is created)
     bool touched_ = true;             // a setter ran since the last call
+    bool fuse_dec_ = false;           // the one-channel decimator inside the display transform's kernel (PEBBLEGPU_FUSE_DEC=1 at creation)
     hipEvent_t chain_end_ = nullptr;  // set when a two-stream call failed half-way: what was queued on the chain stream, for the main stream to wait on
     std::vector<ChanCtl> ctl_;
     bool am_list_dirty_ = true, sm_dirty_ = true;

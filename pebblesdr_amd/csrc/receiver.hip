@@ -31,6 +31,7 @@ int Receiver::create(const pebblegpu_config *cfg)
     PG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     PG_HIP(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
     { const char *e = getenv("PEBBLEGPU_PIPELINE"); pipeline_ = e && e[0] == '1'; }
+    { const char *e = getenv("PEBBLEGPU_FUSE_DEC"); fuse_dec_ = e && e[0] == '1'; }
     for (auto &row : tm.ev)
         for (auto &e : row) PG_HIP(hipEventCreate(&e));
 
@@ -79,6 +80,7 @@ int Receiver::create(const pebblegpu_config *cfg)
         if (int rc = spec_.init(S, nf, bins)) return rc;
         bins = spec_.bins;
         PG_HIP(hipMalloc((void **)&d_spec, sizeof(float) * (size_t)(max_n / nf) * bins * S));
+        if (spec_.dec_ready() && nf == 2048) { if (int rc = dec_.set_fuse_window(spec_.d_window, spec_.h_window)) return rc; }  // the decimator may run inside the transform's kernel
     }
     zoom_bins = cfg->hires_bins;
     if (zoom_bins) {  // m_fftHiRes->fftParams(m_numHiResSpectrumBins, maxDb, m_hiResSampleRate, numSamples, BLACKMANHARRIS), signalspectrum.cpp:59
@@ -389,8 +391,16 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             if (side && hipEventRecord(ev[6], cs) == hipSuccess) r->chain_end_ = ev[6];
         }
     } guard{this, ev, cs, side, true};
+    // One channel through hb11 x 8, hb15, hb23, hb47 beside the 8192-bin transform: the transform's workgroups can compute the decimator
+    // from the frames they hold (k_spectrum_t128<.., DEC>): the stream crosses HBM once, nothing is written at the intermediate rates.
+    // Opt-in (PEBBLEGPU_FUSE_DEC=1 when the receiver is created): measured slower -- the stages sit in the kernel's barrier intervals,
+    // 0.297 ms against 0.247 beside the stand-alone first stage, the call 0.330 against 0.293
+    dec_.want_lds_free = side;
+    const bool fuse_dec = fuse_dec_ && side && with_chain && !pipeline_ && S == 1 && spec_.dec_ready() && nf == 2048 && dec_.spectrum_can_run(osc_) && (!raw || !staged);
+    DecFuse df;
+    if (fuse_dec) { if (int rc = dec_.fill_dec_fuse(&df, osc_, (long long)n)) return rc; }
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
-        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec, raw)) return rc;
+        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec, raw, fuse_dec ? &df : nullptr)) return rc;
         last_spec_frames = n / nf;
         if (smeter_on) {
             const long long F = (long long)(n / nf);
@@ -412,7 +422,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
     dec_.want_lds_free = side;
     // an event record costs the stream a ~5 us bubble: per-kernel events only when asked for (set_profiling)
-    if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw)) return rc;
+    if (fuse_dec) {
+        if (int rc = dec_.run_beside_spectrum(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, raw)) return rc;
+        PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));  // everything behind the decimator reads what the transform's kernel wrote
+    } else if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw)) return rc;
     if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
     const long long nd = dec_.out_len();
     if (zoom_bins) {  // SignalSpectrum::zoomed(m_sampleBuf, numStepSamples), receiver.cpp:884 / :942 (the update timer forced open)
@@ -509,7 +522,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         // join: the call has ended once both pipelines have, and it ends on the chain's stream.  That stream is the main stream
         // of the next call (the two swap roles): its first kernel then follows this call's last in queue order, where a wait
         // on an event from the other queue cost ~25 us of idle GPU per call
-        PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+        if (!fuse_dec) PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
         PG_HIP(hipEventRecord(ev[6], cs));
         std::swap(stream_, chain_stream_);
         last_end_ = ev[6];

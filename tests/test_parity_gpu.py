@@ -412,7 +412,7 @@ def test_config1_variant_8192_fastfir(gpu_lib, oracle_mod):
     assert got == 3
 
 
-@pytest.mark.parametrize("route", ["default", "one-wave transform, pipelined calls"])
+@pytest.mark.parametrize("route", ["default", "one-wave transform, pipelined calls", "decimator inside the display transform"])
 def test_config2_wfm_with_spectrum(gpu_lib, oracle_mod, monkeypatch, route):
     """BASELINE config 2 (the bench workload) at parity size: 20 Msps HackRF-shape int8 IQ, 1 channel, mixer +1 MHz,
     chain hb11x8,hb15,hb23,hb47 -> 312.5 kHz, WFM mono, 8192-bin spectrum on every 2048-sample frame.
@@ -421,11 +421,13 @@ def test_config2_wfm_with_spectrum(gpu_lib, oracle_mod, monkeypatch, route):
     Second route: the opt-in kernel on the one-wave transform (fft_w64.h) with calls that do not join their two streams."""
     import pebblesdr_amd as P
     fs, n = 20_000_000, 2048
-    if route != "default":
+    if route.startswith("one-wave"):
         monkeypatch.setenv("PEBBLEGPU_SPECTRUM_W64", "1")
         monkeypatch.setenv("PEBBLEGPU_PIPELINE", "1")
+    elif route.startswith("decimator"):  # k_spectrum_t128<.., DEC>: mixer + hb11 x 8, hb15, hb23, hb47 in the transform's workgroups (opt-in)
+        monkeypatch.setenv("PEBBLEGPU_FUSE_DEC", "1")
     rx = P.ReceiverBank(fs, 1, True, True, 8192, max_superframes=4)
-    assert rx.kernel_name(1) == ("k_spectrum_t128" if route == "default" else "k_spectrum_w64")
+    assert rx.kernel_name(1) == ("k_spectrum_w64" if route.startswith("one-wave") else "k_spectrum_t128")
     assert rx.chain() == [(11, 8), (15, 2), (23, 2), (47, 2)] and rx.D == 64 and rx.info.demod_rate == 312500.0
     rx.set_mixer(0, 1.0e6)
     sf = rx.superframe
@@ -446,6 +448,8 @@ def test_config2_wfm_with_spectrum(gpu_lib, oracle_mod, monkeypatch, route):
         a, s = rx.process(x[lo:hi])
         ga.append(a[0]); gs.append(s[0])
     ga, gs = np.concatenate(ga), np.concatenate(gs)
+    if route.startswith("decimator"):  # (the first call sits in the oscillator's transient and takes the general kernels; the others are fused)
+        assert rx.kernel_name(2) == "k_spectrum_t128 (decimator inside)"
     assert ga.shape == ra.shape and gs.shape == rs.shape
     for k in range(6):
         assert rel_rms(ga[k * 2048:(k + 1) * 2048], ra[k * 2048:(k + 1) * 2048]) <= TOL
@@ -1611,7 +1615,9 @@ def test_squelch_in_a_bank(gpu_lib, oracle_mod):
 @pytest.mark.parametrize("fmt,dtype,scale,order,w64", [(0, np.int8, 128.0, 0, 0), (1, np.uint8, 128.0, 1, 0), (2, np.int16, 32768.0, 0, 0),
                                                        (4, np.int16, 32767.0, 3, 0), (3, np.float32, 1.0, 1, 0),
                                                        (0, np.int8, 128.0, 1, 1), (1, np.uint8, 128.0, 0, 1), (2, np.int16, 32768.0, 2, 1),
-                                                       (4, np.int16, 32767.0, 0, 1), (3, np.float32, 1.0, 0, 1)])
+                                                       (4, np.int16, 32767.0, 0, 1), (3, np.float32, 1.0, 0, 1),
+                                                       (0, np.int8, 128.0, 3, 2), (1, np.uint8, 128.0, 2, 2), (2, np.int16, 32768.0, 1, 2),
+                                                       (4, np.int16, 32767.0, 3, 2), (3, np.float32, 1.0, 0, 2)])
 def test_process_raw_converting_in_the_first_loads(gpu_lib, monkeypatch, fmt, dtype, scale, order, w64):
     """The bench's own shape fed in the device's sample format: at 20 Msps / 8192 bins / one channel the display transform and the
     first decimator stage read the raw pairs themselves (k_spectrum_t128<.., RAW>, k_mix_hb11_lean<RAW>: no float2 copy of the
@@ -1620,8 +1626,10 @@ def test_process_raw_converting_in_the_first_loads(gpu_lib, monkeypatch, fmt, dt
     calls, so the second one's first windows come from the history the first one left."""
     import pebblesdr_amd as P
     fs, bins = 20_000_000, 8192
-    if w64:  # the opt-in display kernel converts in its loads as well (k_spectrum_w64<FMT>)
+    if w64 == 1:  # the opt-in display kernel converts in its loads as well (k_spectrum_w64<FMT>)
         monkeypatch.setenv("PEBBLEGPU_SPECTRUM_W64", "1")
+    elif w64 == 2:  # ... and so does the display transform that also runs the decimator (k_spectrum_t128<2, FMT, DEC>)
+        monkeypatch.setenv("PEBBLEGPU_FUSE_DEC", "1")
     a = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
     b = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
     for rx in (a, b):
@@ -1648,7 +1656,8 @@ def test_process_raw_converting_in_the_first_loads(gpu_lib, monkeypatch, fmt, dt
             buf.free()
         gb, sb = b.process(x[lo:hi])
         if lo:  # (the first call of a fresh receiver sits inside the oscillator's amplitude transient and takes the general route)
-            assert a.kernel_name(2) == "k_mix_hb11_lean" and a.kernel_name(1) == ("k_spectrum_w64" if w64 else "k_spectrum_t128")
+            assert a.kernel_name(2) == ("k_spectrum_t128 (decimator inside)" if w64 == 2 else "k_mix_hb11_lean")
+            assert a.kernel_name(1) == ("k_spectrum_w64" if w64 == 1 else "k_spectrum_t128")
         assert np.abs(ga).max() > 1e-3
         assert np.array_equal(ga, gb)
         assert np.array_equal(sa, sb)
@@ -1658,8 +1667,7 @@ def test_pipelined_calls_run_back_to_back_and_match_joined_calls(gpu_lib, monkey
     """PEBBLEGPU_PIPELINE=1: successive calls no longer join their two streams -- the display transforms follow one another on
     one stream, the chains on the other, and a call's tail runs beside the next call's transform.  Five calls queued without
     a host synchronisation in between, a retune before the fourth (a setter makes the next call join first, so the change
-    lands between the right two calls): audio bit for bit what a receiver that joins every call gives, spectrum of the last
-    call as well (same kernels on both sides)."""
+    lands between the right two calls): audio and spectrum bit for bit what a receiver that joins every call gives (same kernels)."""
     import pebblesdr_amd as P
     fs, bins = 20_000_000, 8192
     monkeypatch.setenv("PEBBLEGPU_PIPELINE", "1")
