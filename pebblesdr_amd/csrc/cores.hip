@@ -499,6 +499,7 @@ int DecimCore::fill_dec_fuse(DecFuse *df, const OscBank &osc, long long n)
     df->gain0 = first.gain;
     df->gain_last = casc.gain;
     df->mix_on = (int)o.mix_on;
+    { static const int dbg = [] { const char *e = getenv("PEBBLEGPU_FUSE_DBG"); return e ? atoi(e) : 0; }(); df->dbg = dbg; }
     for (int p = 0; p < 11; p++) df->step[p] = o.step[p];
     {
         double ph = 2048.0 * o.inc;

@@ -254,6 +254,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     float r0n[7];
     float2 phn = make_float2(0.f, 0.f);
     auto dec_prefetch = [&](int td2) {  // (every work-item: a conditional request would keep the old values alive through the transform)
+        if (df.dbg & 1) return;
 #pragma unroll
         for (int i = 0; i < 7; i++) r0n[i] = df.r0tab[256 * i + (td2 & 255)];
         phn = df.ph_scratch[((long long)blockIdx.x * HALVES + half) * 256 + (td2 & 255)];
@@ -315,7 +316,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         const bool dec_run = DEC && live;          // (f == -1 included: the look-back frame)
         const bool dec_emit = dec_run && it >= 0;  // outputs of the chain's own frames leave the kernel
         const int par = (int)(f & 1);
-        if (dec_run) {
+        if (dec_run && !(df.dbg & 2)) {
             if (td < 256) {
                 // first stage: y0[jf] = ph * sum_d (h[d] step[d]) x[8 jf - 10 + d], the samples read windowed and un-windowed by the tap
                 // (taps and oscillator come from memory every frame: nothing of the decimator is held in registers through the transform)
@@ -358,6 +359,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
             if (emit && part == 0) df.y[32 * fr + m] = cscale(acc, df.gain_last);
         };
         auto dec_slot = [&](int k) {
+            if (df.dbg & 4) return;
             if (k == 1) {
                 if (dec_run && td >= 256 && td < 384) {  // hb15 over z0
                     const int m = td - 256;

@@ -214,6 +214,7 @@ struct DecFuse {
     double phase0, inc;      // oscillator at input sample n of the call: a_inf e^{j 2 pi (phase0 + (n + 1) inc)}
     float a_inf, gain0, gain_last;
     int mix_on;
+    int dbg;                 // timing experiments only (PEBBLEGPU_FUSE_DBG): 1 no table / oscillator loads, 2 no first stage, 4 no halfbands
     float2 step[11];         // e^{j 2 pi d inc}
     float2 wfr;              // e^{j 2 pi 2048 inc}: an output's oscillator from one frame to the next
     float2 *ph_scratch;      // [chains][256]: the first stage's oscillator per output, carried from frame to frame of a chain (L2-resident)
