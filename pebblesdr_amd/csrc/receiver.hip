@@ -80,7 +80,7 @@ int Receiver::create(const pebblegpu_config *cfg)
         if (int rc = spec_.init(S, nf, bins)) return rc;
         bins = spec_.bins;
         PG_HIP(hipMalloc((void **)&d_spec, sizeof(float) * (size_t)(max_n / nf) * bins * S));
-        if (spec_.dec_ready() && nf == 2048) { if (int rc = dec_.set_fuse_window(spec_.d_window, spec_.h_window)) return rc; }  // the decimator may run inside the transform's kernel
+        if (fuse_dec_ && spec_.dec_ready() && nf == 2048) { if (int rc = dec_.set_fuse_window(spec_.d_window, spec_.h_window)) return rc; }  // (opt-in) the decimator may run inside the transform's kernel
     }
     zoom_bins = cfg->hires_bins;
     if (zoom_bins) {  // m_fftHiRes->fftParams(m_numHiResSpectrumBins, maxDb, m_hiResSampleRate, numSamples, BLACKMANHARRIS), signalspectrum.cpp:59
@@ -371,7 +371,9 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // straight behind a still-busy stream starts exactly where the previous call ended: it takes that call's end event as its
     // start instead of recording one.
     hipEvent_t start = ev[0];
-    static const bool lean_events = [] { const char *e = getenv("PEBBLEGPU_EVENTS"); return !(e && e[0] == 'f'); }();  // =full: every call records its own start, joins at its end (A/B)
+    // (opt-in, PEBBLEGPU_EVENTS=lean: saves one packet per call, ~6 us of the 17 between two calls, but the call's first kernel then no
+    // longer has an event of its own in front of it -- last_ms(1), the bench's roofline time of the display transform, would include the gap)
+    static const bool lean_events = [] { const char *e = getenv("PEBBLEGPU_EVENTS"); return e && e[0] == 'l'; }();
     if (lean_events && side && !pipeline_ && !was_touched && !staged && last_end_ && hipStreamQuery(stream_) == hipErrorNotReady) start = last_end_;
     else PG_HIP(hipEventRecord(ev[0], stream_));
     tm.start_ev[slot] = start;
