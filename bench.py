@@ -114,6 +114,51 @@ def pmc_traffic(superframes):
     return None, None
 
 
+def socket_power(step, sync, seconds=2.5):
+    """Socket power (rocm-smi) while the workload's steps are queued back to back for a couple of seconds, untimed: whether the
+    kernel the roofline prices runs against the chip's power limit rather than a pipe's.  Returns {"busy_W", "idle_W"} or None
+    when rocm-smi is not there to ask."""
+    import shutil
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+
+    def read():
+        try:
+            out = subprocess.run([exe, "--showpower"], capture_output=True, text=True, timeout=20).stdout
+        except Exception:
+            return None
+        for line in out.splitlines():
+            if "(W):" in line:
+                try:
+                    return float(line.split("(W):")[1])
+                except ValueError:
+                    return None
+        return None
+
+    sync()
+    idle = read()
+    stop = threading.Event()
+
+    def work():
+        while not stop.is_set():
+            for _ in range(50):
+                step()
+            sync()
+
+    th = threading.Thread(target=work)
+    th.start()
+    time.sleep(seconds * 0.5)
+    busy = [read() for _ in range(2)]
+    stop.set()
+    th.join()
+    busy = [b for b in busy if b is not None]
+    if not busy:
+        return None
+    return {"busy_W": round(sum(busy) / len(busy), 0), "idle_W": idle, "how": "rocm-smi --showpower, twice, ~1.3 s into an untimed run of back-to-back steps"}
+
+
 def settle(step, sync, max_s=0.5, batch=20):
     """Untimed steps until the step time stops falling.  After an idle spell (set-up, a host-side pause) the GPU's clocks take
     tens of milliseconds of sustained load to come up: the first 40 steps of the headline workload run at 0.35 ms, from step
@@ -432,6 +477,7 @@ def main():
             pcie = pcie_inclusive(P, rx, n, device)
     del raw8
     rx_info = {"frames": n // NF}
+    power = socket_power(step, rx.synchronize) if (rank == 0 and world == 1 and not args.headline_only) else None
     copy_gbps = None
     if rank == 0:
         try:
@@ -473,6 +519,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_spectrum_t128", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_peak_GBs": copy_gbps,
+                         "socket_power": power,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(spec_ms, 4),
                          "rest_of_chain_ms": round(chain_ms, 4),
                          "co_scheduled": "the chain runs on a second stream beside this kernel (its first stage needs no LDS)",
