@@ -1701,3 +1701,40 @@ def test_pipelined_calls_run_back_to_back_and_match_joined_calls(gpu_lib, monkey
     finally:
         for bf in bufs:
             bf.free()
+
+
+def test_decimator_inside_the_display_transform_switches_routes_with_a_retune(gpu_lib, monkeypatch):
+    """PEBBLEGPU_FUSE_DEC=1: calls inside an oscillator transient (the first one, the one after a retune) take the stand-alone
+    kernels, the others run the decimator inside k_spectrum_t128 -- each route leaves what the other needs in front of the next call
+    (windowed last frame one way; first-stage tail and mixed-sample history the other).  Six calls of uneven length with a retune
+    before the fourth, against a receiver that only ever uses the stand-alone kernels: audio within the parity tolerance on every
+    call (4.7e-8 measured), spectra bit for bit."""
+    import pebblesdr_amd as P
+    fs, bins = 20_000_000, 8192
+    monkeypatch.setenv("PEBBLEGPU_FUSE_DEC", "1")
+    a = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=3)
+    monkeypatch.delenv("PEBBLEGPU_FUSE_DEC")
+    b = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=3)
+    for rx in (a, b):
+        rx.set_mixer(0, 1.0e6)
+    sf = a.superframe
+    lens = [1, 2, 3, 1, 3, 2]
+    N = sum(lens) * sf
+    t = np.arange(N) / fs
+    x = (0.4 * np.exp(1j * (2 * np.pi * 1.0e6 * t + 75.0 * np.sin(2 * np.pi * 1000 * t))) + lcg_noise(N, 11, 1e-2)).astype(np.complex64)
+    lo, routes = 0, []
+    for k, m in enumerate(lens):
+        if k == 3:
+            for rx in (a, b):
+                rx.set_mixer(0, 1.15e6)
+        seg = x[lo:lo + m * sf]
+        lo += m * sf
+        ga, sa = a.process(seg)
+        gb, sb = b.process(seg)
+        routes.append(a.kernel_name(2))
+        assert b.kernel_name(2) != "k_spectrum_t128 (decimator inside)"
+        assert np.abs(gb).max() > 1e-3
+        assert rel_rms(ga, gb) <= TOL, "call %d" % k
+        assert np.array_equal(sa, sb), "call %d" % k
+    fused = "k_spectrum_t128 (decimator inside)"
+    assert routes[0] != fused and routes[1] == fused and routes[2] == fused and routes[3] != fused and routes[4] == fused and routes[5] == fused
