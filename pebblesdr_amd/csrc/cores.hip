@@ -457,8 +457,8 @@ void DecimCore::release()
         if (d_xtail_w[i]) (void)hipFree(d_xtail_w[i]);
         d_xtail_w[i] = nullptr;
     }
-    if (d_r0tab) (void)hipFree(d_r0tab);
-    d_r0tab = nullptr;
+    if (d_c0tab) (void)hipFree(d_c0tab);
+    d_c0tab = nullptr;
     if (d_ph_scratch) (void)hipFree(d_ph_scratch);
     d_ph_scratch = nullptr;
     ph_cap = 0;
@@ -471,17 +471,19 @@ int DecimCore::set_fuse_window(const float *d_window, const std::vector<float> &
     std::vector<float> t(7 * 256);
     for (int i = 0; i < 7; i++)
         for (int jf = 0; jf < 256; jf++) t[256 * i + jf] = bank_taps.h[kD[i]] / w[(8 * jf - 10 + kD[i]) & 2047];
-    if (!d_r0tab) PG_HIP(hipMalloc((void **)&d_r0tab, sizeof(float) * t.size()));
-    PG_HIP(hipMemcpy(d_r0tab, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
+    h_r0 = t;
+    h_c0.assign(t.size(), make_float2(0.f, 0.f));
+    c0_valid = false;
+    if (!d_c0tab) PG_HIP(hipMalloc((void **)&d_c0tab, sizeof(float2) * t.size()));
     fuse_window = d_window;
     return 0;
 }
 bool DecimCore::shape_for_spectrum() const
 {
     return C == 1 && bank_front && !fused_all && !fused_front && !wide && first.stride == 8 && casc.nst == 3 && casc.stride[0] == 2 && casc.stride[1] == 2 &&
-           casc.stride[2] == 2 && casc.ntaps[0] == 15 && casc.ntaps[1] == 23 && casc.ntaps[2] == 47 && buf0.hist <= 256 && d_xtail_w[0] != nullptr && d_r0tab != nullptr;
+           casc.stride[2] == 2 && casc.ntaps[0] == 15 && casc.ntaps[1] == 23 && casc.ntaps[2] == 47 && buf0.hist <= 256 && d_xtail_w[0] != nullptr && d_c0tab != nullptr;
 }
-int DecimCore::fill_dec_fuse(DecFuse *df, const OscBank &osc, long long n)
+int DecimCore::fill_dec_fuse(hipStream_t s, DecFuse *df, const OscBank &osc, long long n)
 {
     if (n <= 0 || n % 2048 != 0) return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a whole number of 2048-sample frames", n);
     len0 = n / first.stride;
@@ -500,13 +502,28 @@ int DecimCore::fill_dec_fuse(DecFuse *df, const OscBank &osc, long long n)
     df->gain_last = casc.gain;
     df->mix_on = (int)o.mix_on;
     { static const int dbg = [] { const char *e = getenv("PEBBLEGPU_FUSE_DBG"); return e ? atoi(e) : 0; }(); df->dbg = dbg; }
-    for (int p = 0; p < 11; p++) df->step[p] = o.step[p];
+    if (!c0_valid || c0_inc != o.inc || c0_mix != (int)o.mix_on) {
+        // (rare: the first such call and the first after a retune.)  The copy is queued on the call's main stream, which follows
+        // everything earlier calls queued on either stream, and waited for: the host table is free to change afterwards
+        static const int kD[7] = {0, 2, 4, 5, 6, 8, 10};
+        for (int i = 0; i < 7; i++)
+            for (int jf = 0; jf < 256; jf++) {
+                const float r = h_r0[256 * i + jf];
+                const float2 st = o.mix_on ? o.step[kD[i]] : make_float2(1.f, 0.f);
+                h_c0[256 * i + jf] = make_float2(r * st.x, r * st.y);
+            }
+        PG_HIP(hipMemcpyAsync(d_c0tab, h_c0.data(), sizeof(float2) * h_c0.size(), hipMemcpyHostToDevice, s));
+        PG_HIP(hipStreamSynchronize(s));
+        c0_valid = true;
+        c0_inc = o.inc;
+        c0_mix = (int)o.mix_on;
+    }
     {
         double ph = 2048.0 * o.inc;
         ph -= std::floor(ph);
         df->wfr = make_float2((float)std::cos(design::kTwoPi * ph), (float)std::sin(design::kTwoPi * ph));
     }
-    df->r0tab = d_r0tab;
+    df->c0tab = d_c0tab;
     {
         // one 2 KiB row per frame chain of the transform's launch (chains of at most 32 frames, at least 512 of them)
         const size_t need = (size_t)(n / 2048 + 1024) * 256;

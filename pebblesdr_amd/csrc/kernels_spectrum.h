@@ -218,8 +218,14 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
                                                                  float *__restrict__ prev_out, SpectrumParams sp, int shift, RawSrc raw,
                                                                  DecFuse df)
 {
-    constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP, XOFF = NF / 2;
+    constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP;
     constexpr int REGION = FftLds<NF>::kSlots;
+    // The parked frame: sample n sits in region n >> 9 at slot XOFF + m (m = n & 511).  DEC: at XOFF + m + (m >> 3) -- one pad slot
+    // per eight samples, so that the first decimator stage's stride-8 reads (all of one residue mod 8: four banks of a plain layout)
+    // spread over the banks with an address that stays affine in the lane -- and each region's last ten samples once more in front
+    // of the next region's first (m = -10 .. -1), so a window never straddles two regions.
+    constexpr int XOFF = NF / 2 + (DEC ? 16 : 0), RSTEP = DEC ? 144 : 128;
+    auto fslot = [](int m) { return XOFF + m + (DEC ? (m >> 3) : 0); };
     constexpr bool RAW = FMT >= 0;
     __shared__ float2 lds_all[HALVES][4][REGION];
     __shared__ float2 tw_lds[kTw128Count];
@@ -250,21 +256,28 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     if (DEC) {
         for (int i = tid; i < (int)(sizeof(DecLds) / sizeof(float2)); i += 512) reinterpret_cast<float2 *>(&dl)[i] = make_float2(0.f, 0.f);
     }
-    // the first stage's taps (against windowed samples) and oscillator for the coming frame: requested one barrier interval ahead
-    float r0n[7];
-    float2 phn = make_float2(0.f, 0.f);
-    auto dec_prefetch = [&](int td2) {  // (every work-item: a conditional request would keep the old values alive through the transform)
-        if (df.dbg & 1) return;
+    // the first stage's taps (against windowed samples, times the oscillator's step per tap) and its oscillator for the coming frame:
+    // requested one barrier interval ahead, by the four waves that use them (the others get zeros: a conditional request alone would
+    // keep the old values alive through the transform)
+    float2 c0n[7], phn;
+    auto dec_prefetch = [&](int td2) {
 #pragma unroll
-        for (int i = 0; i < 7; i++) r0n[i] = df.r0tab[256 * i + (td2 & 255)];
-        phn = df.ph_scratch[((long long)blockIdx.x * HALVES + half) * 256 + (td2 & 255)];
+        for (int i = 0; i < 7; i++) c0n[i] = make_float2(0.f, 0.f);
+        phn = make_float2(0.f, 0.f);
+        if (td2 < 256 && !(df.dbg & 1)) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) c0n[i] = df.c0tab[256 * i + td2];
+            phn = df.ph_scratch[((long long)blockIdx.x * HALVES + half) * 256 + td2];
+        }
     };
     if (DEC) dec_prefetch(tid);
     auto park = [&](int tt) {  // sample n = tt + 512 i goes to region i, slot XOFF + tt (RAW: n = 4 tt + i: region tt / 128, four adjacent slots)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if (RAW) lds[tt >> 7][XOFF + ((4 * tt + i) & 511)] = cscale(xn[i], win[i]);
-            else lds[i][XOFF + tt] = cscale(xn[i], win[i]);
+            const int reg = RAW ? tt >> 7 : i, m = RAW ? (4 * tt + i) & 511 : tt;
+            const float2 v = cscale(xn[i], win[i]);
+            lds[reg][fslot(m)] = v;
+            if (DEC && m >= 502 && reg < 3) lds[reg + 1][fslot(m - 512)] = v;
         }
     };
     {
@@ -272,7 +285,11 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         if (DEC && f0 == 0) {
             // the call's first chain: the frame in front of the call, kept windowed by the previous call's last workgroup
 #pragma unroll
-            for (int i = 0; i < 4; i++) lds[i][XOFF + tid] = df.xtail[tid + 512 * i];
+            for (int i = 0; i < 4; i++) {
+                const float2 v = df.xtail[tid + 512 * i];
+                lds[i][fslot(tid)] = v;
+                if (tid >= 502 && i < 3) lds[i + 1][fslot(tid - 512)] = v;
+            }
         } else if (ff < sp.n_frames) {
             if (RAW) {
                 raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + ff * NF + 4 * tid, xn);
@@ -295,7 +312,8 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         opaque(td);
         // (DEC: the call's first chain starts on the frame in front of the call, so its frame 0 is fetched like any other)
         const bool fetch = it + 1 < G && f + 1 < sp.n_frames && (f >= 0 || DEC);
-        if (fetch) {
+        auto fetch_next = [&]() {
+            if (!fetch) return;
             if (RAW) {
                 raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + (f + 1) * NF + 4 * td, xn);
             } else {
@@ -303,13 +321,16 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
                 for (int i = 0; i < 4; i++) xn[i] = xp[512 * i];
             }
-        }
+        };
+        // (DEC: the first decimator stage below waits for its prefetched taps; vector-memory results come back in issue order, so the
+        // next frame is requested behind it -- in front it would make that wait last until the frame has come in from HBM)
+        if (!DEC) fetch_next();
         float2 v[E];
         if (xform) {
-            const float2 *gp = &lds[0][XOFF + t];
+            const float2 *gp = &lds[0][fslot(t)];
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const float2 xv = gp[((128 * m) / SL) * REGION + (128 * m) % SL];
+                const float2 xv = gp[(m / 4) * REGION + (m % 4) * RSTEP];
                 v[m] = cmul(bq[m], cmul(tw_lane, xv));
             }
         }
@@ -326,20 +347,21 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
                     ph = ((it + 1) & 7) == 0 ? cscale(cis_cycles(df.phase0 + (double)((long long)NF * f + 8 * td - 9) * df.inc), df.a_inf * df.gain0) : cmul(df.wfr, phn);
                     df.ph_scratch[((long long)blockIdx.x * HALVES + half) * 256 + td] = ph;
                 }
-                float2 acc = make_float2(0.f, 0.f);
+                // lane l of wave w: samples 512 w + 8 l + c, c = d - 10 <= 0: region w, slot XOFF + 9 l + c + floor(c / 8) -- affine, also
+                // for the few in front of the region (its copy of the previous region's end; for w = 0 the previous frame's: xt)
+                const float2 *fb = &lds[td >> 6][XOFF + 9 * (td & 63)];
+                v2f_t acc = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 7; i++) {
-                    const int n = 8 * td - 10 + kD[i];
-                    const float2 xs = n >= 0 ? lds[n >> 9][XOFF + (n & 511)] : dl.xt[par ^ 1][n + 10];
-                    const float2 xr = cscale(xs, r0n[i]);
-                    acc = (i == 0 || !df.mix_on) ? cadd(acc, xr) : cadd(acc, cmul(df.step[kD[i]], xr));
+                    const int c = kD[i] - 10, n = 8 * td + c;
+                    const float2 xs = n >= 0 ? fb[c + (c >> 3)] : dl.xt[par ^ 1][n + 10];
+                    acc = cmac_pk(acc, v2f_t{c0n[i].x, c0n[i].y}, v2f_t{xs.x, xs.y});
                 }
-                const float2 y0 = cmul(ph, acc);
+                const float2 y0 = cmul(ph, make_float2(acc.x, acc.y));
                 dl.z0[14 + td] = y0;
                 if (dec_emit && f == sp.n_frames - 1) df.y0_tail[td] = y0;
             } else if (td < 266) {
-                const int n = NF - 10 + (td - 256);
-                dl.xt[par][td - 256] = lds[n >> 9][XOFF + (n & 511)];
+                dl.xt[par][td - 256] = lds[3][fslot(502 + td - 256)];
             }
         }
         // The decimator's later stages in the transform's barrier intervals, each on waves of its own.  Interval 1: hb15 of this frame
@@ -388,6 +410,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
                 if (dec_run && td >= 384 && td < 406) dl.z1[td - 384] = dl.z1[128 + td - 384];  // its head for the next frame
             }
         };
+        if (DEC) fetch_next();
         __syncthreads();  // A
         if (live && f < 0) {
             const float *pp = prev_in + (long long)s * BINS + ZP * t + q;

@@ -215,10 +215,10 @@ struct DecFuse {
     float a_inf, gain0, gain_last;
     int mix_on;
     int dbg;                 // timing experiments only (PEBBLEGPU_FUSE_DBG): 1 no table / oscillator loads, 2 no first stage, 4 no halfbands
-    float2 step[11];         // e^{j 2 pi d inc}
     float2 wfr;              // e^{j 2 pi 2048 inc}: an output's oscillator from one frame to the next
     float2 *ph_scratch;      // [chains][256]: the first stage's oscillator per output, carried from frame to frame of a chain (L2-resident)
-    const float *r0tab;      // [7][256]: h0[d] / w[8 jf - 10 + d] for the seven non-zero taps d = 0 2 4 5 6 8 10 (taps against WINDOWED samples)
+    const float2 *c0tab;     // [7][256]: step[d] h0[d] / w[8 jf - 10 + d] for the seven non-zero taps d = 0 2 4 5 6 8 10: the first stage's taps against
+                             // WINDOWED samples with the oscillator's advance over the window folded in (rebuilt on a retune)
 };
 
 struct SpectrumParams {

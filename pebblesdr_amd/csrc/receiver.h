@@ -118,14 +118,19 @@ struct DecimCore {
     float2 *d_xtail_w[2] = {nullptr, nullptr};     // [2048] ping-pong
     int xtail_parity = 0;
     const float *fuse_window = nullptr;            // the display transform's window (set by the owner; nullptr: never fused)
-    float *d_r0tab = nullptr;                      // [7][256] first-stage taps over that window (DecFuse::r0tab)
+    float2 *d_c0tab = nullptr;                     // [7][256] first-stage taps over that window times the oscillator's step per tap (DecFuse::c0tab)
+    std::vector<float> h_r0;                       // ... the real part of it: h0[d] / w[n]
+    std::vector<float2> h_c0;
+    bool c0_valid = false;
+    double c0_inc = 0;
+    int c0_mix = 0;
     float2 *d_ph_scratch = nullptr;                // DecFuse::ph_scratch
     size_t ph_cap = 0;
     int set_fuse_window(const float *d_window, const std::vector<float> &w);  // the owner's display transform uses this window
     bool shape_for_spectrum() const;               // the chain is the one the kernel is built for
     bool spectrum_can_run(const OscBank &osc) const { return shape_for_spectrum() && fuse_window && want_lds_free && !osc.any_transient(); }
     // fills the kernel's parameter block for a call of n samples (before the transform is launched)
-    int fill_dec_fuse(DecFuse *df, const OscBank &osc, long long n);
+    int fill_dec_fuse(hipStream_t s, DecFuse *df, const OscBank &osc, long long n);
     // what is left for the chain's stream in such a call: the mixed-sample history for a later general call (two workgroups)
     int run_beside_spectrum(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc, const RawSrc *raw);
     int hist_parity = 0;

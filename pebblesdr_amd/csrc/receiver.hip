@@ -400,7 +400,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     dec_.want_lds_free = side;
     const bool fuse_dec = fuse_dec_ && side && with_chain && !pipeline_ && S == 1 && spec_.dec_ready() && nf == 2048 && dec_.spectrum_can_run(osc_) && (!raw || !staged);
     DecFuse df;
-    if (fuse_dec) { if (int rc = dec_.fill_dec_fuse(&df, osc_, (long long)n)) return rc; }
+    if (fuse_dec) { if (int rc = dec_.fill_dec_fuse(stream_, &df, osc_, (long long)n)) return rc; }
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
         if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec, raw, fuse_dec ? &df : nullptr)) return rc;
         last_spec_frames = n / nf;
