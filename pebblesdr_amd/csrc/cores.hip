@@ -118,6 +118,27 @@ int make_twiddles_t128(float2 **d_tw)
     return 0;
 }
 
+// k_spectrum_t128 (8192 bins = four transforms x[n] W_8192^{n q} of a 2048-sample frame): one such table per q with the per-work-item
+// part of that factor, W_8192^{t q}, folded in -- pass B's entries times W_8192^{16 q << e}, pass C's times W_8192^{q << e}
+int make_twiddles_t128q(float2 **d_tw)
+{
+    std::vector<float2> t2((size_t)4 * kTw128Count);
+    auto W = [](long long idx) {
+        const double a = -design::kTwoPi * (double)(idx % 8192) / 8192.0;
+        return make_float2((float)std::cos(a), (float)std::sin(a));
+    };
+    for (int q = 0; q < 4; q++) {
+        float2 *t = t2.data() + (size_t)q * kTw128Count;
+        for (int k = 0; k < 16; k++)
+            for (int e = 0; e < 3; e++) t[kTw128B + e * 16 + k] = W((long long)(64 * k + 16 * q) << e);
+        for (int k = 0; k < 128; k++)
+            for (int e = 0; e < 4; e++) t[kTw128C + e * 128 + k] = W((long long)(4 * k + q) << e);
+    }
+    PG_HIP(hipMalloc((void **)d_tw, sizeof(float2) * t2.size()));
+    PG_HIP(hipMemcpy(*d_tw, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // OscBank
 // ------------------------------------------------------------------------------------------------
@@ -1513,7 +1534,7 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
             }
         PG_HIP(hipMalloc((void **)&d_btab128, sizeof(float2) * b2.size()));
         PG_HIP(hipMemcpy(d_btab128, b2.data(), sizeof(float2) * b2.size(), hipMemcpyHostToDevice));
-        if (int rc = make_twiddles_t128(&d_tw128)) return rc;
+        if (int rc = make_twiddles_t128q(&d_tw128)) return rc;  // (k_spectrum_t128's own: one table per q)
     }
     scale = (float)(1.0 / (cg * (double)nf));  // /coherentGain then /maxBinPower, fft.cpp:347,355
     if (int rc = make_twiddles(2048, &d_tw_nf)) return rc;

@@ -40,8 +40,16 @@ __device__ __forceinline__ void dft16(float2 *u)
 
 // sync(): a barrier over (at least) the 128 work-items of this transform, executed by all of them.
 // DO_LDS / DO_MATH exist for tools/ubench/fft_core.hip only (the exchanges alone, the butterflies alone); kernels use the defaults.
-template <class Sync, bool DO_LDS = true, bool DO_MATH = true>
-__device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const float2 *__restrict__ tw, int t, Sync sync)
+// The seven table entries of a work-item, held by the caller (REGS: nothing is read from tw).  A caller that transforms
+// x[n] W_M^{n q} (the pruned zero-padded transform) can fold the per-work-item part of that factor, W_M^{t q}, into these: behind
+// pass A it is W^{q r} per butterfly input r of pass B times a factor common to the butterfly, which is W^{q m} per register m of
+// pass C -- both power series like the twiddles themselves (kernels_spectrum.h, make_twiddles_t128q).
+struct Tw128Regs {
+    float2 b1, b2, b4, c1, c2, c4, c8;
+};
+
+template <class Sync, bool DO_LDS = true, bool DO_MATH = true, bool REGS = false>
+__device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const float2 *__restrict__ tw, int t, Sync sync, Tw128Regs wr = Tw128Regs())
 {
     // ---- pass A: radix 16, the 16 strided elements of a work-item are one butterfly; output k -> element 16 t + k ----
     if (DO_MATH) dft16(x);
@@ -54,7 +62,9 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
     // ---- pass B: radix 8, P = 16, two butterflies ----
     {
         const int k = t & 15;
-        const float2 w1 = tw[kTw128B + k], w2 = tw[kTw128B + 16 + k], w4 = tw[kTw128B + 32 + k];
+        float2 w1, w2, w4;
+        if (REGS) { w1 = wr.b1; w2 = wr.b2; w4 = wr.b4; }
+        else { w1 = tw[kTw128B + k]; w2 = tw[kTw128B + 16 + k]; w4 = tw[kTw128B + 32 + k]; }
         if (DO_LDS) {
             const float2 *rp = lds + lpad4(t);  // lpad4(t + 128 m) = lpad4(t) + 136 m
 #pragma unroll
@@ -87,7 +97,9 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
     sync();
     // ---- pass C: radix 16, P = 128 = T, k = t; output r -> element t + 128 r (the register layout) ----
     {
-        const float2 w1 = tw[kTw128C + t], w2 = tw[kTw128C + 128 + t], w4 = tw[kTw128C + 256 + t], w8 = tw[kTw128C + 384 + t];
+        float2 w1, w2, w4, w8;
+        if (REGS) { w1 = wr.c1; w2 = wr.c2; w4 = wr.c4; w8 = wr.c8; }
+        else { w1 = tw[kTw128C + t]; w2 = tw[kTw128C + 128 + t]; w4 = tw[kTw128C + 256 + t]; w8 = tw[kTw128C + 384 + t]; }
         if (DO_LDS) {
             const float2 *rp = lds + lpad(t);  // lpad(t + 128 m) = lpad(t) + 144 m
 #pragma unroll

@@ -228,7 +228,6 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     auto fslot = [](int m) { return XOFF + m + (DEC ? (m >> 3) : 0); };
     constexpr bool RAW = FMT >= 0;
     __shared__ float2 lds_all[HALVES][4][REGION];
-    __shared__ float2 tw_lds[kTw128Count];
     __shared__ DecLds dec_all[DEC ? HALVES : 1];
     const int tid = threadIdx.x & 511, lane = tid & 63;
     const int half = HALVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0;
@@ -242,13 +241,21 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     float *y = out + (long long)s * sp.out_pitch;
     float2 *my = lds[q];
     float *stage = reinterpret_cast<float *>(my);
-    for (int i = threadIdx.x; i < kTw128Count; i += 512 * HALVES) tw_lds[i] = tw128[i];
     float win[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) win[i] = RAW ? window[4 * tid + i] : window[tid + 512 * i];
     const int t0 = (wave & 1) * 64 + lane;                                   // work-item of its transform, 0..127
-    const float2 tw_lane = cis_cycles(-(double)(t0 * q) / (double)BINS);     // W_bins^{t q}
+    // The pre-twiddle W_bins^{n q}, n = t + 128 m: its wave-uniform part W_bins^{128 m q} multiplies the samples; its per-work-item part
+    // W_bins^{t q} costs nothing -- it is folded into the transform's own twiddles (tw128: one table per q, make_twiddles_t128q), which
+    // a work-item reads once and keeps
     const float2 *bq = btab128 + q * E;                                      // W_bins^{128 m q}, m < 16 (wave-uniform)
+    Tw128Regs twr;
+    {
+        const float2 *tq = tw128 + q * kTw128Count;
+        const int kb = t0 & 15;
+        twr.b1 = tq[kTw128B + kb]; twr.b2 = tq[kTw128B + 16 + kb]; twr.b4 = tq[kTw128B + 32 + kb];
+        twr.c1 = tq[kTw128C + t0]; twr.c2 = tq[kTw128C + 128 + t0]; twr.c4 = tq[kTw128C + 256 + t0]; twr.c8 = tq[kTw128C + 384 + t0];
+    }
     const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float pa[E];
     float2 xn[4];
@@ -331,7 +338,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 const float2 xv = gp[(m / 4) * REGION + (m % 4) * RSTEP];
-                v[m] = cmul(bq[m], cmul(tw_lane, xv));
+                v[m] = cmul(bq[m], xv);
             }
         }
         const bool dec_run = DEC && live;          // (f == -1 included: the look-back frame)
@@ -420,10 +427,11 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         // every work-item of the workgroup takes the same path below (xform is uniform): the barriers inside match
         if (xform) {
             int slot = 0;
-            fft2048_t128(v, my, tw_lds, t, [&] {
+            auto bar = [&] {
                 __syncthreads();
                 if (DEC) dec_slot(++slot);
-            });
+            };
+            fft2048_t128<decltype(bar), true, true, true>(v, my, tw128, t, bar, twr);
             float *st = stage + t;
             float mag[E];
 #pragma unroll

@@ -36,6 +36,7 @@ void fill_scan_section(ScanSection &s, int type, const double *c);
 int scan_warm_subchunks(const ScanSection *secs, int nsec, double tol);
 int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
+int make_twiddles_t128q(float2 **d_tw);  // four tables, the pruned transform's per-work-item factor folded in (k_spectrum_t128)
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa = nullptr);
 int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa);  // 0, or a failure code (too many / too deep)
 int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale = 0.f);
