@@ -46,9 +46,18 @@ __device__ __forceinline__ void dft16(float2 *u)
 // pass C -- both power series like the twiddles themselves (kernels_spectrum.h, make_twiddles_t128q).
 struct Tw128Regs {
     float2 b1, b2, b4, c1, c2, c4, c8;
+    float2 cx[16];  // FULLC: all fifteen twiddles of pass C (cx[m] for register m: the very products the pass would form), formed once by the caller
 };
+__device__ __forceinline__ void tw128_fill_cx(Tw128Regs &w)
+{
+    w.cx[0] = make_float2(1.f, 0.f);
+    w.cx[1] = w.c1; w.cx[2] = w.c2; w.cx[3] = cmul_pk(w.c1, w.c2); w.cx[4] = w.c4;
+    w.cx[5] = cmul_pk(w.c4, w.c1); w.cx[6] = cmul_pk(w.c4, w.c2); w.cx[7] = cmul_pk(w.c4, w.cx[3]); w.cx[8] = w.c8;
+#pragma unroll
+    for (int i = 1; i < 8; i++) w.cx[8 + i] = cmul_pk(w.c8, w.cx[i]);
+}
 
-template <class Sync, bool DO_LDS = true, bool DO_MATH = true, bool REGS = false>
+template <class Sync, bool DO_LDS = true, bool DO_MATH = true, bool REGS = false, bool FULLC = false>
 __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const float2 *__restrict__ tw, int t, Sync sync, Tw128Regs wr = Tw128Regs())
 {
     // ---- pass A: radix 16, the 16 strided elements of a work-item are one butterfly; output k -> element 16 t + k ----
@@ -107,12 +116,17 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
         }
         sync();  // the image may be overwritten (the caller parks its results there)
         if (!DO_MATH) return;
+        if (REGS && FULLC) {
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = cmul_pk(wr.cx[m], x[m]);
+        } else {
         const float2 w3 = cmul_pk(w1, w2), w5 = cmul_pk(w4, w1), w6 = cmul_pk(w4, w2), w7 = cmul_pk(w4, w3);
         x[1] = cmul_pk(w1, x[1]); x[2] = cmul_pk(w2, x[2]); x[3] = cmul_pk(w3, x[3]); x[4] = cmul_pk(w4, x[4]);
         x[5] = cmul_pk(w5, x[5]); x[6] = cmul_pk(w6, x[6]); x[7] = cmul_pk(w7, x[7]); x[8] = cmul_pk(w8, x[8]);
         x[9] = cmul_pk(cmul_pk(w8, w1), x[9]); x[10] = cmul_pk(cmul_pk(w8, w2), x[10]); x[11] = cmul_pk(cmul_pk(w8, w3), x[11]);
         x[12] = cmul_pk(cmul_pk(w8, w4), x[12]); x[13] = cmul_pk(cmul_pk(w8, w5), x[13]); x[14] = cmul_pk(cmul_pk(w8, w6), x[14]);
         x[15] = cmul_pk(cmul_pk(w8, w7), x[15]);
+        }
         dft16(x);
         float2 y[16];
 #pragma unroll

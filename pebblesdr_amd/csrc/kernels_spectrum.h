@@ -211,7 +211,9 @@ struct DecLds {
     float2 z0[14 + 256], z1[22 + 128], z2[2][46 + 64], xt[2][10];  // (z2 twice: hb47 runs a frame behind hb23, which is writing the next one)
 };
 
-template <int HALVES, int FMT, bool DEC = false>
+// FULLC: pass C's fifteen twiddles per work-item formed once and held (126 registers: four such waves fill a SIMD's register file --
+// for calls whose first decimator stage does not run beside this kernel, Receiver::process).
+template <int HALVES, int FMT, bool DEC = false, bool FULLC = false>
 static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t128(const float2 *__restrict__ in, float *__restrict__ out,
                                                                  const float *__restrict__ window, const float2 *__restrict__ btab128,
                                                                  const float2 *__restrict__ tw128, const float *__restrict__ prev_in,
@@ -255,6 +257,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         const int kb = t0 & 15;
         twr.b1 = tq[kTw128B + kb]; twr.b2 = tq[kTw128B + 16 + kb]; twr.b4 = tq[kTw128B + 32 + kb];
         twr.c1 = tq[kTw128C + t0]; twr.c2 = tq[kTw128C + 128 + t0]; twr.c4 = tq[kTw128C + 256 + t0]; twr.c8 = tq[kTw128C + 384 + t0];
+        if (FULLC) tw128_fill_cx(twr);
     }
     const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float pa[E];
@@ -431,7 +434,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
                 __syncthreads();
                 if (DEC) dec_slot(++slot);
             };
-            fft2048_t128<decltype(bar), true, true, true>(v, my, tw128, t, bar, twr);
+            fft2048_t128<decltype(bar), true, true, true, FULLC>(v, my, tw128, t, bar, twr);
             float *st = stage + t;
             float mag[E];
 #pragma unroll

@@ -320,6 +320,7 @@ struct SpectrumCore {
     float2 *d_btab128 = nullptr, *d_tw128 = nullptr;  // the same for the two-wave transform (fft_t128.h), 8192 bins
     float2 *d_ftab = nullptr;         // [bins/nf][nf] window[n] * W_bins^{n q}: the one factor per point of k_spectrum_q128
     std::vector<float> h_window;      // host copy of the window (the decimator's taps against windowed samples)
+    bool last_fullc = false;          // the last run used k_spectrum_t128's register-held twiddles (nothing ran beside it)
     bool use_w64 = false;             // 8192 bins on k_spectrum_w64 (PEBBLEGPU_SPECTRUM_W64=1 when the core is created)
     int stagger = 0, pad_lds = 0;     // k_spectrum_t128: barrier intervals between the two halves of a 1024-item workgroup (0: 512-item workgroups)
     bool per_q = false;               // k_spectrum_q128 (one transform per 128-item workgroup) instead of the shared-frame kernels
@@ -331,7 +332,7 @@ struct SpectrumCore {
     int parity = 0;
     int init(uint32_t streams, uint32_t frame, uint32_t fft_size);
     void release();
-    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, const RawSrc *raw = nullptr, const DecFuse *df = nullptr);
+    int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, const RawSrc *raw = nullptr, const DecFuse *df = nullptr, bool nothing_beside = false);
     bool dec_ready() const { return !big && !per_q && bins == 8192 && !use_w64; }  // k_spectrum_t128<.., DEC> exists for this plan
     bool raw_ready() const { return !big && !per_q && bins == 8192; }  // k_spectrum_t128 converts in its loads
 };

@@ -402,7 +402,8 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     DecFuse df;
     if (fuse_dec) { if (int rc = dec_.fill_dec_fuse(stream_, &df, osc_, (long long)n)) return rc; }
     if (with_spectrum) {  // SignalSpectrum::unprocessed on the raw frame, receiver.cpp:826
-        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec, raw, fuse_dec ? &df : nullptr)) return rc;
+        // (a call whose chain follows on the same stream, or that has none, leaves the GPU to the transform: its all-registers variant)
+        if (int rc = spec_.run(stream_, d_iq, in_pitch, (long long)(n / nf), d_spec, raw, fuse_dec ? &df : nullptr, !side)) return rc;
         last_spec_frames = n / nf;
         if (smeter_on) {
             const long long F = (long long)(n / nf);
@@ -553,7 +554,7 @@ int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, ui
 const char *Receiver::kernel_name(int which) const
 {
     switch (which) {
-    case 1: return !bins ? "" : spec_.big ? "k_big_cols + k_big_rows" : spec_.per_q ? "k_spectrum_q128" : bins == 8192 ? (spec_.use_w64 ? "k_spectrum_w64" : "k_spectrum_t128") : bins == 4096 ? "k_spectrum<2>" : "k_spectrum_1to1";
+    case 1: return !bins ? "" : spec_.big ? "k_big_cols + k_big_rows" : spec_.per_q ? "k_spectrum_q128" : bins == 8192 ? (spec_.use_w64 ? "k_spectrum_w64" : spec_.last_fullc ? "k_spectrum_t128 (twiddles held)" : "k_spectrum_t128") : bins == 4096 ? "k_spectrum<2>" : "k_spectrum_1to1";
     case 2: return dec_.front_name;
     case 3: return dec_.rest_name;
     case 4: return wfm ? "" : ff_n == 2048 ? "k_fastfir_t128" : "k_fastfir";

@@ -413,7 +413,7 @@ int pebblegpu_spectrum_process(pebblegpu_spectrum *s, const double *in, int n, d
     int ov = 0;  // m_isOverload: any |re| or |im| above m_overLimit = 0.9 (fft.cpp:137-140), flagged on the host copy
     for (int i = 0; i < 2 * n; i++) if (std::fabs(in[i]) > 0.9) { ov = 1; break; }
     if (int rc = s->up(s->d_in, in, (size_t)n)) return rc;
-    if (int rc = s->sp.run(s->stream, s->d_in, n, 1, s->d_out)) return rc;
+    if (int rc = s->sp.run(s->stream, s->d_in, n, 1, s->d_out, nullptr, nullptr, true)) return rc;  // (a step on its own stream: nothing beside it)
     PG_HIP(hipStreamSynchronize(s->stream));
     s->hs.resize(s->sp.bins);
     PG_HIP(hipMemcpy(s->hs.data(), s->d_out, sizeof(float) * s->sp.bins, hipMemcpyDeviceToHost));

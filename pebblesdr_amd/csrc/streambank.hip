@@ -105,7 +105,7 @@ int pebblegpu_streambank_process(pebblegpu_streambank *sb, const void *d_iq, uin
     PG_HIP(hipEventRecord(sb->ev[1], sb->stream));
     if (what & 2u) {
         const long long F = (long long)(n / sb->cfg.frame);
-        if (int rc = sb->sp.run(sb->stream, in, (long long)n, F, sb->d_spec)) return rc;
+        if (int rc = sb->sp.run(sb->stream, in, (long long)n, F, sb->d_spec, nullptr, nullptr, true)) return rc;  // (one stream: nothing runs beside the transform)
         sb->last_frames = (uint64_t)F;
     }
     PG_HIP(hipEventRecord(sb->ev[2], sb->stream));
