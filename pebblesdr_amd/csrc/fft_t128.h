@@ -57,7 +57,9 @@ __device__ __forceinline__ void tw128_fill_cx(Tw128Regs &w)
     for (int i = 1; i < 8; i++) w.cx[8 + i] = cmul_pk(w.c8, w.cx[i]);
 }
 
-template <class Sync, bool DO_LDS = true, bool DO_MATH = true, bool REGS = false, bool FULLC = false>
+// HELD (REGS, not FULLC): the first HELD of pass C's seven products w8 * w_i come from wr.cx[9 ..] (formed once by the caller) -- as many
+// as the caller's register budget allows
+template <class Sync, bool DO_LDS = true, bool DO_MATH = true, bool REGS = false, bool FULLC = false, int HELD = 0>
 __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const float2 *__restrict__ tw, int t, Sync sync, Tw128Regs wr = Tw128Regs())
 {
     // ---- pass A: radix 16, the 16 strided elements of a work-item are one butterfly; output k -> element 16 t + k ----
@@ -123,9 +125,13 @@ __device__ __forceinline__ void fft2048_t128(float2 (&x)[16], float2 *lds, const
         const float2 w3 = cmul_pk(w1, w2), w5 = cmul_pk(w4, w1), w6 = cmul_pk(w4, w2), w7 = cmul_pk(w4, w3);
         x[1] = cmul_pk(w1, x[1]); x[2] = cmul_pk(w2, x[2]); x[3] = cmul_pk(w3, x[3]); x[4] = cmul_pk(w4, x[4]);
         x[5] = cmul_pk(w5, x[5]); x[6] = cmul_pk(w6, x[6]); x[7] = cmul_pk(w7, x[7]); x[8] = cmul_pk(w8, x[8]);
-        x[9] = cmul_pk(cmul_pk(w8, w1), x[9]); x[10] = cmul_pk(cmul_pk(w8, w2), x[10]); x[11] = cmul_pk(cmul_pk(w8, w3), x[11]);
-        x[12] = cmul_pk(cmul_pk(w8, w4), x[12]); x[13] = cmul_pk(cmul_pk(w8, w5), x[13]); x[14] = cmul_pk(cmul_pk(w8, w6), x[14]);
-        x[15] = cmul_pk(cmul_pk(w8, w7), x[15]);
+        x[9] = cmul_pk(REGS && HELD >= 1 ? wr.cx[9] : cmul_pk(w8, w1), x[9]);
+        x[10] = cmul_pk(REGS && HELD >= 2 ? wr.cx[10] : cmul_pk(w8, w2), x[10]);
+        x[11] = cmul_pk(REGS && HELD >= 3 ? wr.cx[11] : cmul_pk(w8, w3), x[11]);
+        x[12] = cmul_pk(REGS && HELD >= 4 ? wr.cx[12] : cmul_pk(w8, w4), x[12]);
+        x[13] = cmul_pk(REGS && HELD >= 5 ? wr.cx[13] : cmul_pk(w8, w5), x[13]);
+        x[14] = cmul_pk(REGS && HELD >= 6 ? wr.cx[14] : cmul_pk(w8, w6), x[14]);
+        x[15] = cmul_pk(REGS && HELD >= 7 ? wr.cx[15] : cmul_pk(w8, w7), x[15]);
         }
         dft16(x);
         float2 y[16];

@@ -222,6 +222,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 {
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP;
     constexpr int REGION = FftLds<NF>::kSlots;
+    constexpr int HELD = (DEC || FULLC) ? 0 : 4;  // products of pass C held beside the seven table entries: what fits under 112 registers (the chain's first stage needs the other 64 of a SIMD's 512)
     // The parked frame: sample n sits in region n >> 9 at slot XOFF + m (m = n & 511).  DEC: at XOFF + m + (m >> 3) -- one pad slot
     // per eight samples, so that the first decimator stage's stride-8 reads (all of one residue mod 8: four banks of a plain layout)
     // spread over the banks with an address that stays affine in the lane -- and each region's last ten samples once more in front
@@ -257,7 +258,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         const int kb = t0 & 15;
         twr.b1 = tq[kTw128B + kb]; twr.b2 = tq[kTw128B + 16 + kb]; twr.b4 = tq[kTw128B + 32 + kb];
         twr.c1 = tq[kTw128C + t0]; twr.c2 = tq[kTw128C + 128 + t0]; twr.c4 = tq[kTw128C + 256 + t0]; twr.c8 = tq[kTw128C + 384 + t0];
-        if (FULLC) tw128_fill_cx(twr);
+        if (FULLC || HELD > 0) tw128_fill_cx(twr);
     }
     const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float pa[E];
@@ -434,7 +435,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
                 __syncthreads();
                 if (DEC) dec_slot(++slot);
             };
-            fft2048_t128<decltype(bar), true, true, true, FULLC>(v, my, tw128, t, bar, twr);
+            fft2048_t128<decltype(bar), true, true, true, FULLC, HELD>(v, my, tw128, t, bar, twr);
             float *st = stage + t;
             float mag[E];
 #pragma unroll
