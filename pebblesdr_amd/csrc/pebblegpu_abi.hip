@@ -220,6 +220,7 @@ int pebblegpu_receiver_synchronize(pebblegpu_receiver *h)
 static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, float *ms)
 {
     if (!h || !ms || which < 0 || which > 5) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = const_cast<pebblegpu_receiver *>(h)->rx.close_timing()) return rc;
     const pg::Timers &t = h->rx.tm;
     if (t.calls == 0) return fail(PEBBLEGPU_E_INVALID, "no call has been made yet");
     if (last_k == 0) last_k = 1;
@@ -233,11 +234,12 @@ static int kernel_ms(const pebblegpu_receiver *h, int which, uint32_t last_k, fl
             return fail(PEBBLEGPU_E_INVALID, "per-kernel times need pebblegpu_receiver_set_profiling(rx, 1) before the calls");
         float one = 0;
         const bool has_mid = t.has_mid[(t.calls - 1 - k) % pg::Timers::kRing];
-        PG_HIP(hipEventSynchronize(ev[6]));
+        const hipEvent_t endev = t.end_ev[(t.calls - 1 - k) % pg::Timers::kRing];
+        PG_HIP(hipEventSynchronize(endev));
         if (has_mid) PG_HIP(hipEventSynchronize(ev[1]));  // pipelined calls: the transform's stream ends on its own
         if (which == 1 && !has_mid) continue;  // no display transform in that call: 0 ms
         const hipEvent_t start = t.start_ev[(t.calls - 1 - k) % pg::Timers::kRing];
-        PG_HIP(hipEventElapsedTime(&one, a[which] == 0 ? start : ev[a[which]], ev[b[which]]));
+        PG_HIP(hipEventElapsedTime(&one, a[which] == 0 ? start : ev[a[which]], b[which] == 6 ? endev : ev[b[which]]));
         if (which == 0 && has_mid) {  // the call lasted until the later of its two pipelines
             float other = 0;
             PG_HIP(hipEventElapsedTime(&other, start, ev[1]));

@@ -342,7 +342,9 @@ struct SpectrumCore {
 struct Timers {
     static constexpr int kRing = 64;
     hipEvent_t ev[kRing][8] = {};
-    hipEvent_t start_ev[kRing] = {};  // where the call began: its own ev[0], or the previous call's end event when it queued straight behind it
+    hipEvent_t start_ev[kRing] = {};  // where the call began (its ev[0])
+    hipEvent_t end_ev[kRing] = {};    // where it ended: its ev[6], or the next call's ev[0] (a side-by-side call records no end of its own)
+    int open_slot = -1;               // the last call's end is not known yet (Receiver::close_timing)
     bool detailed[kRing] = {};   // per-kernel events (2..5) were recorded for that call
     bool has_mid[kRing] = {};    // event 1 (behind the display transform) was recorded: calls without a spectrum skip it unless profiling
     uint64_t calls = 0;
@@ -364,6 +366,7 @@ public:
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain, const RawSrc *raw = nullptr);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();
+    int close_timing();  // records the end event a side-by-side call left out (no-op otherwise)
     const char *kernel_name(int which) const;  // the kernels behind pebblegpu_receiver_last_ms's groups, as last run
 
     int device = 0;
@@ -419,7 +422,6 @@ private:
     // No events of its own: the chain stream waits for the call's start event, the call's end event is recorded on the chain
     // stream once it has also seen the transform's end event, and whatever next touches the main stream (the next call, a
     // synchronise) first waits for that end event.  Every event record costs the stream ~5 us, so none is spent on the fork/join.
-    hipEvent_t last_end_ = nullptr;   // the previous call's end event, recorded on what is now the main stream (a call queued behind a busy stream starts there)
     hipEvent_t spec_end_ = nullptr;   // pipelined calls: the last display transform queued on the main stream (for the chain's stream to wait on at a join)
     bool pipeline_ = false;           // successive side-by-side calls overlap (PEBBLEGPU_PIPELINE=1 when the receiver is created)
     bool touched_ = true;             // a setter ran since the last call

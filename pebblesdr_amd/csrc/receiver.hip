@@ -367,17 +367,17 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     hipEvent_t *ev = tm.slot();
     const int slot = (int)(tm.calls % Timers::kRing);
     tm.calls++;
-    // Every event record is a packet of its own in the queue (~6 us of idle GPU between two kernels).  A side-by-side call queued
-    // straight behind a still-busy stream starts exactly where the previous call ended: it takes that call's end event as its
-    // start instead of recording one.
+    // Every event record is a packet of its own in the queue (~6 us of idle GPU between two kernels).  A side-by-side call therefore
+    // records no end event: it ends where the next call's start event is recorded (same queue, nothing in between), or where
+    // sync() / a timing query closes it (close_timing).
     hipEvent_t start = ev[0];
-    // (opt-in, PEBBLEGPU_EVENTS=lean: saves one packet per call, ~6 us of the 17 between two calls, but the call's first kernel then no
-    // longer has an event of its own in front of it -- last_ms(1), the bench's roofline time of the display transform, would include the gap)
-    static const bool lean_events = [] { const char *e = getenv("PEBBLEGPU_EVENTS"); return e && e[0] == 'l'; }();
-    if (lean_events && side && !pipeline_ && !was_touched && !staged && last_end_ && hipStreamQuery(stream_) == hipErrorNotReady) start = last_end_;
-    else PG_HIP(hipEventRecord(ev[0], stream_));
+    PG_HIP(hipEventRecord(ev[0], stream_));
     tm.start_ev[slot] = start;
-    last_end_ = nullptr;
+    if (tm.open_slot >= 0) {
+        tm.end_ev[tm.open_slot] = ev[0];
+        tm.open_slot = -1;
+    }
+    tm.end_ev[slot] = ev[6];
     hipStream_t cs = side ? chain_stream_ : stream_;
     if (side) {
         PG_HIP(hipStreamWaitEvent(chain_stream_, start, 0));  // fork: the input is ready where the call starts
@@ -418,7 +418,6 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (!with_chain) {
         if (profile_detail) for (int i = 2; i <= 5; i++) PG_HIP(hipEventRecord(ev[i], stream_));
         PG_HIP(hipEventRecord(ev[6], stream_));
-        last_end_ = ev[6];
         guard.armed = false;
         return 0;
     }
@@ -526,12 +525,12 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         // of the next call (the two swap roles): its first kernel then follows this call's last in queue order, where a wait
         // on an event from the other queue cost ~25 us of idle GPU per call
         if (!fuse_dec) PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
-        PG_HIP(hipEventRecord(ev[6], cs));
+        static const bool end_records = [] { const char *e = getenv("PEBBLEGPU_EVENTS"); return e && e[0] == 'f'; }();  // =full: an end record per call (A/B)
+        if (end_records) PG_HIP(hipEventRecord(ev[6], cs));
+        else tm.open_slot = slot;  // (closed by the next call's start record, by sync() or by a timing query)
         std::swap(stream_, chain_stream_);
-        last_end_ = ev[6];
     } else {
         PG_HIP(hipEventRecord(ev[6], stream_));
-        last_end_ = ev[6];
     }
     osc_.advance(n);
     guard.armed = false;
@@ -563,9 +562,20 @@ const char *Receiver::kernel_name(int which) const
     }
 }
 
+int Receiver::close_timing()
+{
+    if (tm.open_slot >= 0) {  // the last side-by-side call recorded no end event: it ended on what is now the main stream
+        PG_HIP(hipEventRecord(tm.ev[tm.open_slot][6], stream_));
+        tm.end_ev[tm.open_slot] = tm.ev[tm.open_slot][6];
+        tm.open_slot = -1;
+    }
+    return 0;
+}
+
 int Receiver::sync()
 {
     PG_HIP(hipSetDevice(device));
+    if (int rc = close_timing()) return rc;
     PG_HIP(hipStreamSynchronize(stream_));
     PG_HIP(hipStreamSynchronize(chain_stream_));
     return 0;
