@@ -476,18 +476,29 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
             }
         }
         if (it >= 0 && live) {
-            const float *sp0 = reinterpret_cast<const float *>(lds[0]) + td;
             float *yf = y + f * (long long)BINS;
+            // (an index of its own per store: the four reads of one store then pair up across the regions, (x, y) and (z, w), and
+            //  land in the store's registers; from one base the compiler pairs them across the stores and spends three moves
+            //  per store on sorting them)
+            int j[NF / 512];
 #pragma unroll
             for (int i = 0; i < NF / 512; i++) {
-                const int j = td + 512 * i;
-                float4 d;
-                d.x = sp0[0 * (REGION * 2) + 512 * i];
-                d.y = sp0[1 * (REGION * 2) + 512 * i];
-                d.z = sp0[2 * (REGION * 2) + 512 * i];
-                d.w = sp0[3 * (REGION * 2) + 512 * i];
-                const int u = (ZP * j + BINS / 2) & (BINS - 1);
-                *reinterpret_cast<float4 *>(yf + u) = d;
+                j[i] = td + 512 * i;
+                opaque(j[i]);
+            }
+            float4 d[NF / 512];
+#pragma unroll
+            for (int i = 0; i < NF / 512; i++) {
+                const float *spi = reinterpret_cast<const float *>(lds[0]) + j[i];
+                d[i].x = spi[0 * (REGION * 2)];
+                d[i].y = spi[1 * (REGION * 2)];
+                d[i].z = spi[2 * (REGION * 2)];
+                d[i].w = spi[3 * (REGION * 2)];
+            }
+#pragma unroll
+            for (int i = 0; i < NF / 512; i++) {
+                const int u = (ZP * j[i] + BINS / 2) & (BINS - 1);
+                *reinterpret_cast<float4 *>(yf + u) = d[i];
             }
         }
         __syncthreads();  // C
