@@ -222,7 +222,9 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 {
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP;
     constexpr int REGION = FftLds<NF>::kSlots;
-    constexpr int HELD = (DEC || FULLC) ? 0 : 4;  // products of pass C held beside the seven table entries: what fits under 112 registers (the chain's first stage needs the other 64 of a SIMD's 512)
+    // products of pass C held beside the seven table entries: what fits under 112 registers (the chain's first stage needs the other
+    // 64 of a SIMD's 512); the raw formats' conversion takes three registers more
+    constexpr int HELD = (DEC || FULLC) ? 0 : (FMT >= 0 ? 5 : 6);
     // The parked frame: sample n sits in region n >> 9 at slot XOFF + m (m = n & 511).  DEC: at XOFF + m + (m >> 3) -- one pad slot
     // per eight samples, so that the first decimator stage's stride-8 reads (all of one residue mod 8: four banks of a plain layout)
     // spread over the banks with an address that stays affine in the lane -- and each region's last ten samples once more in front
@@ -314,7 +316,10 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     __syncthreads();
     if (HALVES > 1 && half == 1)
         for (int i = 0; i < shift; i++) __syncthreads();  // the second half runs `shift` intervals behind (same barrier count overall)
-    for (int it = -1; it < G; it++) {
+    // One iteration; `pa` holds the previous frame's magnitudes on entry and `pn` takes this frame's.  The loop below calls it twice per
+    // round with the two arrays exchanged: a magnitude is then produced in the registers it is read from a frame later, and the
+    // sixteen register moves a single carried array costs per frame are gone (DEC: one array, in place -- its loop is the longer one).
+    auto iteration = [&](const int it, float (&pa)[E], float (&pn)[E]) __attribute__((always_inline)) {
         const long long f = f0 + it;
         const bool live = f < sp.n_frames;   // workgroup-uniform
         const bool xform = live && f >= 0;
@@ -445,7 +450,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 const float a = mag[m] + pa[m];
-                pa[m] = mag[m];
+                pn[m] = mag[m];
                 mag[m] = a;
             }
 #pragma unroll
@@ -455,13 +460,19 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
             if (f == sp.n_frames - 1) {
                 float *pp = prev_out + (long long)s * BINS + ZP * t + q;
 #pragma unroll
-                for (int m = 0; m < E; m++) pp[ZP * 128 * m] = pa[m];
+                for (int m = 0; m < E; m++) pp[ZP * 128 * m] = pn[m];
             }
-        } else if (HALVES > 1 || DEC) {  // the halves share every barrier: an iteration without a transform still passes its four
+        } else {
+            if (HALVES > 1 || DEC) {  // the halves share every barrier: an iteration without a transform still passes its four
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                __syncthreads();
-                if (DEC) dec_slot(i + 1);
+                for (int i = 0; i < 4; i++) {
+                    __syncthreads();
+                    if (DEC) dec_slot(i + 1);
+                }
+            }
+            if (!DEC) {
+#pragma unroll
+                for (int m = 0; m < E; m++) pn[m] = pa[m];
             }
         }
         __syncthreads();  // B
@@ -502,6 +513,16 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
             }
         }
         __syncthreads();  // C
+    };
+    if (DEC) {
+        for (int it = -1; it < G; it++) iteration(it, pa, pa);
+    } else {
+        float pb[E];
+        for (int it = -1; it < G; it += 2) {
+            iteration(it, pa, pb);
+            if (it + 1 >= G) break;
+            iteration(it + 1, pb, pa);
+        }
     }
     if (DEC) {  // hb47 of the chain's last frame (its input complete since the last iteration's second interval, several barriers ago)
         const long long fl = f0 + G - 1;
