@@ -620,7 +620,7 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
 }
 
 // The one-channel form of the above that runs BESIDE the spectrum kernel (receiver.hip, two-stream call).  That kernel's
-// workgroups hold 4 x 112 of a SIMD's 512 registers per lane and all but 3.6 KiB of a CU's LDS for the whole launch, so a
+// workgroups hold 4 x 112 of a SIMD's 512 registers per lane and 144 of a CU's 160 KiB of LDS for the whole launch, so a
 // neighbour has to live in 64 registers and no LDS or it only gets onto a CU by displacing one of them.  Lean by
 // construction: lanes = consecutive outputs (coalesced stores, no transpose tile); only outputs whose window lies inside
 // the call (j >= j_first; the first one or two and the mixed history for the next call come from a small launch of
