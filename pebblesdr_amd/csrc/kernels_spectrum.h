@@ -347,7 +347,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 const float2 xv = gp[(m / 4) * REGION + (m % 4) * RSTEP];
-                v[m] = cmul(bq[m], xv);
+                v[m] = m == 0 ? xv : cmul(bq[m], xv);  // (bq[0] = 1)
             }
         }
         const bool dec_run = DEC && live;          // (f == -1 included: the look-back frame)
