@@ -223,8 +223,8 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     constexpr int NF = 2048, ZP = 4, BINS = NF * ZP, E = 16, SL = NF / ZP;
     constexpr int REGION = FftLds<NF>::kSlots;
     // products of pass C held beside the seven table entries: what fits under 112 registers (the chain's first stage needs the other
-    // 64 of a SIMD's 512); the raw formats' conversion takes three registers more
-    constexpr int HELD = (DEC || FULLC) ? 0 : (FMT >= 0 ? 5 : 6);
+    // 64 of a SIMD's 512); raw float samples wait for their conversion in eight registers, not four
+    constexpr int HELD = (DEC || FULLC) ? 0 : (FMT == 3 ? 5 : FMT >= 0 ? 7 : 6);  // (the integer formats wait in two or four)
     // The parked frame: sample n sits in region n >> 9 at slot XOFF + m (m = n & 511).  DEC: at XOFF + m + (m >> 3) -- one pad slot
     // per eight samples, so that the first decimator stage's stride-8 reads (all of one residue mod 8: four banks of a plain layout)
     // spread over the banks with an address that stays affine in the lane -- and each region's last ten samples once more in front
@@ -265,6 +265,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
     float pa[E];
     float2 xn[4];
+    RawQuad<FMT < 0 ? 0 : FMT> xr;  // RAW: the next frame's samples as fetched; converted where they are parked (park)
     constexpr int kD[7] = {0, 2, 4, 5, 6, 8, 10};  // the hb11's non-zero taps (DEC)
     if (DEC) {
         for (int i = tid; i < (int)(sizeof(DecLds) / sizeof(float2)); i += 512) reinterpret_cast<float2 *>(&dl)[i] = make_float2(0.f, 0.f);
@@ -285,6 +286,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     };
     if (DEC) dec_prefetch(tid);
     auto park = [&](int tt) {  // sample n = tt + 512 i goes to region i, slot XOFF + tt (RAW: n = 4 tt + i: region tt / 128, four adjacent slots)
+        if (RAW) raw_convert4<FMT < 0 ? 0 : FMT>(raw, xr, xn);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int reg = RAW ? tt >> 7 : i, m = RAW ? (4 * tt + i) & 511 : tt;
@@ -305,7 +307,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
             }
         } else if (ff < sp.n_frames) {
             if (RAW) {
-                raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + ff * NF + 4 * tid, xn);
+                raw_fetch4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + ff * NF + 4 * tid, xr);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++) xn[i] = x[ff * NF + tid + 512 * i];
@@ -331,7 +333,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
         auto fetch_next = [&]() {
             if (!fetch) return;
             if (RAW) {
-                raw_load4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + (f + 1) * NF + 4 * td, xn);
+                raw_fetch4<FMT < 0 ? 0 : FMT>(raw, (long long)s * sp.in_pitch + (f + 1) * NF + 4 * td, xr);
             } else {
                 const float2 *xp = x + (f + 1) * NF + td;
 #pragma unroll

@@ -130,27 +130,44 @@ __device__ __forceinline__ float2 raw_load(const RawSrc &r, long long i)
     return make_float2((r.order & 1) == 0 ? a : b, (r.order == 1 || r.order == 2) ? a : b);
 }
 
-// four consecutive samples i .. i + 3 (i a multiple of 4) in one or two wide loads: 8 bytes for the int8 formats, 16 for int16, 32 for float
+// four consecutive samples i .. i + 3 (i a multiple of 4) in one or two wide loads: 8 bytes for the int8 formats, 16 for int16, 32 for float.
+// In two steps, so that a kernel can hold the words as they came (2, 4 or 8 registers) and convert where it uses the samples: a
+// conversion behind the load makes the compiler wait for the load there.
 template <int FMT>
-__device__ __forceinline__ void raw_load4(const RawSrc &r, long long i, float2 (&o)[4])
+struct RawQuad {
+    uint4 a, b;  // 8-bit formats: a.x, a.y; 16-bit: a; float: a, b
+};
+template <int FMT>
+__device__ __forceinline__ void raw_fetch4(const RawSrc &r, long long i, RawQuad<FMT> &w)
+{
+    if (FMT == 0 || FMT == 1) {
+        const uint2 v = reinterpret_cast<const uint2 *>(r.base)[i >> 2];
+        w.a.x = v.x; w.a.y = v.y;
+    } else if (FMT == 2 || FMT == 4) {
+        w.a = reinterpret_cast<const uint4 *>(r.base)[i >> 2];
+    } else {
+        w.a = reinterpret_cast<const uint4 *>(r.base)[i >> 1];
+        w.b = reinterpret_cast<const uint4 *>(r.base)[(i >> 1) + 1];
+    }
+}
+template <int FMT>
+__device__ __forceinline__ void raw_convert4(const RawSrc &r, const RawQuad<FMT> &w, float2 (&o)[4])
 {
     float v[8];
     if (FMT == 0 || FMT == 1) {
-        const uint2 w = reinterpret_cast<const uint2 *>(r.base)[i >> 2];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const unsigned word = k < 4 ? w.x : w.y;
+            const unsigned word = k < 4 ? w.a.x : w.a.y;
             const int sh = 8 * (k & 3);
             v[k] = FMT == 0 ? (float)((int)(word << (24 - sh)) >> 24) : (float)((word >> sh) & 0xFFu) - 128.0f;
         }
     } else if (FMT == 2 || FMT == 4) {
-        const uint4 w = reinterpret_cast<const uint4 *>(r.base)[i >> 2];
-        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+        const unsigned ww[4] = {w.a.x, w.a.y, w.a.z, w.a.w};
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k] = (float)((int)(ww[k >> 1] << (16 - 16 * (k & 1))) >> 16);
     } else {
-        const float4 a = reinterpret_cast<const float4 *>(r.base)[i >> 1], b = reinterpret_cast<const float4 *>(r.base)[(i >> 1) + 1];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[0] = __uint_as_float(w.a.x); v[1] = __uint_as_float(w.a.y); v[2] = __uint_as_float(w.a.z); v[3] = __uint_as_float(w.a.w);
+        v[4] = __uint_as_float(w.b.x); v[5] = __uint_as_float(w.b.y); v[6] = __uint_as_float(w.b.z); v[7] = __uint_as_float(w.b.w);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -158,9 +175,14 @@ __device__ __forceinline__ void raw_load4(const RawSrc &r, long long i, float2 (
         o[k] = make_float2((r.order & 1) == 0 ? a : b, (r.order == 1 || r.order == 2) ? a : b);
     }
 }
+template <int FMT>
+__device__ __forceinline__ void raw_load4(const RawSrc &r, long long i, float2 (&o)[4])
+{
+    RawQuad<FMT> w;
+    raw_fetch4<FMT>(r, i, w);
+    raw_convert4<FMT>(r, w, o);
+}
 
-// the same for any EVEN sample index i (the first stage's windows start at S j - 10): the chunk is then only 4-byte (int8
-// formats) or 8-byte (int16) aligned, which the global-memory path takes in one wide load all the same
 template <int FMT>
 __device__ __forceinline__ void raw_load4_even(const RawSrc &r, long long i, float2 (&o)[4])
 {
