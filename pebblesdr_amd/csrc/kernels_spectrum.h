@@ -511,7 +511,8 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
             for (int i = 0; i < NF / 512; i++) {
                 const int u = (ZP * j[i] + BINS / 2) & (BINS - 1);
-                *reinterpret_cast<float4 *>(yf + u) = d[i];
+                typedef float v4f_t __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4f_t{d[i].x, d[i].y, d[i].z, d[i].w}, reinterpret_cast<v4f_t *>(yf + u));
             }
         }
         __syncthreads();  // C
