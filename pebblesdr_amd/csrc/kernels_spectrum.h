@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256, 2) void k_spectrum(const float2 *__restrict__ 
                 for (int qq = 0; qq < ZP; qq++) db[qq] = sp0[qq * (REGION * 2) + TG * i];
                 // bin k = ZP*j + qq unfolds to (k + BINS/2) mod BINS (fft.cpp:207-213); the ZP bins stay adjacent
                 const int u = (ZP * j + BINS / 2) & (BINS - 1);
-                if (ZP == 4) *reinterpret_cast<float4 *>(yf + u) = make_float4(db[0], db[1], db[2], db[3]);
-                else if (ZP == 2) *reinterpret_cast<float2 *>(yf + u) = make_float2(db[0], db[1]);
-                else yf[u] = db[0];
+                if (ZP == 4) store_stream(reinterpret_cast<float4 *>(yf + u), make_float4(db[0], db[1], db[2], db[3]));
+                else if (ZP == 2) store_stream(reinterpret_cast<float2 *>(yf + u), make_float2(db[0], db[1]));
+                else store_stream(yf + u, db[0]);
             }
         }
         __syncthreads();  // C: next frame parked, dB slices consumed
@@ -511,8 +511,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
 #pragma unroll
             for (int i = 0; i < NF / 512; i++) {
                 const int u = (ZP * j[i] + BINS / 2) & (BINS - 1);
-                typedef float v4f_t __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(v4f_t{d[i].x, d[i].y, d[i].z, d[i].w}, reinterpret_cast<v4f_t *>(yf + u));
+                store_stream(reinterpret_cast<float4 *>(yf + u), d[i]);
             }
         }
         __syncthreads();  // C
@@ -708,8 +707,8 @@ static __global__ __launch_bounds__(256, 2) void k_spectrum_w64(const float2 *__
                 const float2 d2 = sp0[2 * (QSTRIDE / 2) + 256 * i], d3 = sp0[3 * (QSTRIDE / 2) + 256 * i];
                 // bin k = ZP*j + q unfolds to (k + BINS/2) mod BINS (fft.cpp:207-213); j is even: the pair never straddles the fold
                 float4 *dst = reinterpret_cast<float4 *>(yf + ((ZP * j + BINS / 2) & (BINS - 1)));
-                dst[0] = make_float4(d0.x, d1.x, d2.x, d3.x);
-                dst[1] = make_float4(d0.y, d1.y, d2.y, d3.y);
+                store_stream(dst, make_float4(d0.x, d1.x, d2.x, d3.x));
+                store_stream(dst + 1, make_float4(d0.y, d1.y, d2.y, d3.y));
             }
         }
         PG_W64_TICK(4)
@@ -901,7 +900,7 @@ static __global__ __launch_bounds__(256, 2) void k_spectrum_1to1(const float2 *_
             float *yf = y + f * (long long)NF;
 #pragma unroll
             for (int m = 0; m < E; m++)  // bin k = ln + 64 m unfolds to (k + NF/2) mod NF (fft.cpp:207-213)
-                yf[(ln + 64 * m + NF / 2) & (NF - 1)] = fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f);
+                store_stream(yf + ((ln + 64 * m + NF / 2) & (NF - 1)), fminf(fmaxf(fmaf(6.02059991327962f, mag[m], db_off), -120.f), 0.f));
         }
         if (f == sp.n_frames - 1) {
             float *pp = prev_out + (long long)s * NF + ln;
@@ -1030,7 +1029,7 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
                 d.z = reinterpret_cast<const float *>(lds[2])[j];
                 d.w = reinterpret_cast<const float *>(lds[3])[j];
                 const int u = (4 * a + 32 * j + kBigN / 2) & (kBigN - 1);  // unfold, fft.cpp:207-213
-                *reinterpret_cast<float4 *>(yf + u) = d;
+                *reinterpret_cast<float4 *>(yf + u) = d;  // (16-byte pieces 128 B apart: not nontemporal -- partial lines, 0.52 -> 0.68 ms per call)
             }
         }
         __syncthreads();
