@@ -234,6 +234,7 @@ static __global__ __launch_bounds__(512 * HALVES, 2 * HALVES) void k_spectrum_t1
     constexpr bool RAW = FMT >= 0;
     __shared__ float2 lds_all[HALVES][4][REGION];
     __shared__ DecLds dec_all[DEC ? HALVES : 1];
+    __builtin_amdgcn_s_setprio(3);  // in front of the first stage's waves beside it: that kernel has slack, this one is the call's length
     const int tid = threadIdx.x & 511, lane = tid & 63;
     const int half = HALVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0;
     float2 (*lds)[REGION] = lds_all[half];
