@@ -6,7 +6,9 @@
 #include "kernels_demod.h"
 #include "kernels_fastfir.h"
 #include "kernels_frontend.h"
+#include <algorithm>
 #include "kernels_fused_dec.h"
+#include "kernels_bank_dec.h"
 #include "kernels_spectrum.h"
 #include "receiver.h"
 
@@ -430,6 +432,16 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
                 PG_HIP(hipMemset(d_xhist[i], 0, sizeof(float2) * 16));
             }
             PG_HIP(hipMalloc((void **)&d_y0stage, sizeof(float2) * (size_t)fused_hy * C));
+            const char *eb = getenv("PEBBLEGPU_BANK_DEC");
+            bank_mfma = !(eb && eb[0] == '0');
+            const char *ew = getenv("PEBBLEGPU_BANK_WAVES");
+            bank_waves = ew ? atoi(ew) : 1;
+            if (bank_waves < 1 || bank_waves > 4) bank_waves = 1;
+            for (int i = 0; i < 2; i++) {
+                PG_HIP(hipMalloc((void **)&d_bank_state[i], sizeof(float2) * (size_t)(FG::N1 + FG::N2 + FG::N3) * C));
+                PG_HIP(hipMemset(d_bank_state[i], 0, sizeof(float2) * (size_t)(FG::N1 + FG::N2 + FG::N3) * C));
+            }
+            bank_state_valid = false;
         }
     }
     const long long len0 = max_in / s0.stride;
@@ -467,6 +479,10 @@ void DecimCore::release()
     }
     if (d_y0stage) (void)hipFree(d_y0stage);
     d_y0stage = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (d_bank_state[i]) (void)hipFree(d_bank_state[i]);
+        d_bank_state[i] = nullptr;
+    }
     buf0.release();
     buf1.release();
     fin.release();
@@ -595,6 +611,8 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     len0 = n / first.stride;
     const HistBuf *src = &buf0;
     last_fused = false;
+    const bool had_bank_state = bank_state_valid;
+    bank_state_valid = false;  // (set again below when this call takes the matrix-pipe route)
     if (fused_all && shared_input && !osc.any_transient()) {
         if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
         len_out = n / (long long)chain.total;
@@ -604,6 +622,106 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             fused_L = e ? atoi(e) : 0;
             if (fused_L < 16) fused_L = -1;  // choose per call
             fused_L &= ~15;
+        }
+        if (bank_mfma && (unsigned long long)n * 8 < 0xFFF00000ull && (unsigned long long)C * (unsigned long long)fin.pitch * 8 < 0xFFF00000ull &&
+            len_out >= 64) {  // (its sample fetches and result stores carry 32-bit byte offsets)
+            // one wave per (32 channels, two chunks): chunk length for about bank_waves waves on each of the 1024 SIMDs
+            constexpr int NP = 4;
+            BankDecParams<NP> bp;
+            memset(&bp, 0, sizeof(bp));
+            const long long g32 = cdiv(C, 32);
+            long long pairs_target = 1024LL * bank_waves / g32;
+            if (pairs_target < 1) pairs_target = 1;
+            // a power of two (it divides the call's 2048 k outputs: the last chunk is a whole one), the nearest to the target above
+            long long L = 16;
+            if (fused_L > 0) {
+                while (L * 2 <= fused_L) L *= 2;
+            } else {
+                const long long want = cdiv(len_out, 2 * pairs_target);
+                while (L < want && L < 2048) L *= 2;
+            }
+            while (len_out % L != 0 && L > 16) L /= 2;
+            bp.n_out = len_out;
+            bp.out_pitch = fin.pitch;
+            bp.y0_pitch = buf0.pitch;
+            bp.n_in = n;
+            bp.S = first.stride;
+            bp.L = (int)L;
+            bp.n_chan = (int)C;
+            bp.n_chunks = (int)cdiv(len_out, L);
+            bp.n_groups = (int)g32;
+            bp.hist_pitch = kMaxTaps;
+            bp.xh = xh_depth;
+            bp.min_off = -10;
+            bp.max_off = 0;
+            bp.a_inf = osc.a_inf;
+            bp.gain = first.gain * casc.gain;
+            bp.ctr1 = -4.0;  // the hb11's centre tap sits on sample S j - 5; the oscillator of sample i is e^{j 2 pi (phase0 + (i + 1) inc)}
+            static const int kE[NP] = {0, 1, 3, 5};
+            for (int p = 0; p < NP; p++) {
+                bp.oa[p] = -5 + kE[p];
+                bp.ob[p] = -5 - kE[p];
+                bp.e[p] = (float)kE[p];
+                bp.g[p] = p == 0 ? 0.5f * bank_taps.h[5] : bank_taps.h[5 + kE[p]];
+            }
+            const long long pairs = cdiv(bp.n_chunks, 2);
+            bp.hist_split = 4;
+            bp.state_in = had_bank_state ? d_bank_state[bank_state_parity] : nullptr;
+            bp.state_out = d_bank_state[bank_state_parity ^ 1];
+            const unsigned n_wg = (unsigned)(8 * cdiv(pairs, 8) * cdiv(g32, 4) + cdiv(g32, 4) * bp.hist_split);  // main workgroups, then the history waves'
+            static unsigned long long *d_clk = nullptr;  // diagnosis only: PEBBLEGPU_BANK_CLK=1 prints the waves' clock counts of every such launch
+            static size_t clk_cap = 0;
+            const char *eclk = getenv("PEBBLEGPU_BANK_CLK");
+            const bool want_clk = eclk && eclk[0] == '1';
+            if (want_clk && clk_cap < (size_t)n_wg * 16) {
+                if (d_clk) (void)hipFree(d_clk);
+                PG_HIP(hipMalloc((void **)&d_clk, sizeof(unsigned long long) * n_wg * 16));
+                clk_cap = (size_t)n_wg * 16;
+            }
+            if (want_clk) PG_HIP(hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * n_wg * 16, s));
+            bp.clk = want_clk ? d_clk : nullptr;
+            const char *edbg = getenv("PEBBLEGPU_BANK_DBG");  // timing experiments (wrong results)
+            const int dbg = edbg ? atoi(edbg) : 0;
+            auto kern = dbg == 1 ? k_mix_dec_mfma<NP, 15, 19, 31, 1> : dbg == 2 ? k_mix_dec_mfma<NP, 15, 19, 31, 2> : dbg == 3 ? k_mix_dec_mfma<NP, 15, 19, 31, 3> : k_mix_dec_mfma<NP, 15, 19, 31, 0>;
+            launch(kern, dim3(n_wg), dim3(256), s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn,
+                   (const float2 *)d_xhist[hist_parity], d_xhist[hist_parity ^ 1], (const float2 *)buf0.data(), d_y0stage, d_hist_mixed[hist_parity ^ 1], bp);
+            PG_HIP(hipGetLastError());
+            if (want_clk) {
+                std::vector<unsigned long long> h((size_t)n_wg * 16);
+                PG_HIP(hipStreamSynchronize(s));
+                PG_HIP(hipMemcpy(h.data(), d_clk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                std::vector<double> per, ghz;
+                std::vector<std::pair<double, size_t>> slow;
+                double mx = 0;
+                for (size_t w = 0; w < (size_t)n_wg * 4; w++)
+                    if (h[4 * w + 2]) {
+                        per.push_back((double)h[4 * w] / (double)h[4 * w + 2]);
+                        ghz.push_back((double)h[4 * w] / ((double)h[4 * w + 1] * 10.0));
+                        slow.push_back({per.back(), w});
+                        if ((double)h[4 * w + 1] > mx) mx = (double)h[4 * w + 1];
+                    }
+                std::sort(per.begin(), per.end());
+                std::sort(ghz.begin(), ghz.end());
+                std::sort(slow.begin(), slow.end());
+                if (!per.empty()) {
+                    fprintf(stderr, "k_mix_dec_mfma: %zu waves, L %d, clocks per block min %.0f median %.0f max %.0f; shader clock median %.2f GHz; longest wave %.1f us\n", per.size(),
+                            bp.L, per.front(), per[per.size() / 2], per.back(), ghz[ghz.size() / 2], mx / 100.0);
+                    fprintf(stderr, "   slowest (clocks per block : workgroup.wave pair):");
+                    for (size_t i = slow.size() > 12 ? slow.size() - 12 : 0; i < slow.size(); i++)
+                        fprintf(stderr, " %.0f:%zu.%zu p%llu", slow[i].first, slow[i].second / 4, slow[i].second % 4, h[4 * slow[i].second + 3]);
+                    size_t over = 0;
+                    for (double v : per) over += v > 1.25 * per[per.size() / 2];
+                    fprintf(stderr, "\n   waves more than 25 %% over the median: %zu\n", over);
+                }
+            }
+            hist_parity ^= 1;
+            bank_state_parity ^= 1;
+            bank_state_valid = true;
+            front_name = "k_mix_dec_mfma";
+            rest_name = "";
+            last_fused = true;
+            if (after_first) PG_HIP(hipEventRecord(after_first, s));
+            return 0;
         }
         long long L = fused_L > 0 ? fused_L : ((len_out * groups / 704 + 15) & ~15LL);  // ~700 four-wave workgroups (measured best on 256 CUs: 96 for configs[2]); every chunk pays a 21-block warm-up
         if (L < 32) L = 32;

@@ -1,0 +1,512 @@
+// kernels_bank_dec.h -- mixer + the WHOLE decimator of a bank of channels tuned off one shared stream, in one kernel of
+// independent single-wave workgroups: no LDS hand-offs between waves, no workgroup barrier, first stage on the matrix pipe.
+// Mixer::processBlock + Decimator::process (pebblelib/mixer.cpp:48-81, decimator.cpp:152-226, 593-659, 695-737).
+//
+// Successor of k_mix_dec_fused (kernels_fused_dec.h: four-wave pipeline with one barrier per block, 0.086 ms per configs[2]
+// call at 2.7 waves per SIMD, VALU active a third of the time, 21 M vector instructions, an LDS ring between the stages).
+//
+// The first stage is a contraction.  With the oscillator factored out of a stage's window (k_mix_hb11_lean) and the
+// window's symmetry used (k_mix_dec_fused),
+//     y0[c][j] = pa_c(j) * sum_p ( g_p cos(th_cp) s_p(j) + g_p sin(th_cp) r_p(j) ),    th_cp = 2 pi inc_c e_p,
+//     s_p(j) = x[ctr(j) + e_p] + x[ctr(j) - e_p],   r_p(j) = j (x[ctr(j) + e_p] - x[ctr(j) - e_p]),
+// where the pairs p run over the symmetric taps of the first stage (hb11 x S: e = 0 1 3 5; a merged CIC3 in front of it:
+// twelve pairs), s_p and r_p do not depend on the channel and the coefficients do not depend on time: a [time x 2 NP] by
+// [2 NP x channel] product of REAL matrices for the real and for the imaginary part.  v_mfma_f32_32x32x2_f32 does it in exact
+// fp32 (a k-ordered fmaf chain, bit for bit) at the vector pipe's own rate but beside it: NP matrix instructions per block of
+// 8 outputs x 32 channels x 2 chunks replace 6 NP / 4 packed FMAs per output and channel, and the shared sums need no LDS
+// (every lane forms ITS element of the A operand from two 4-byte loads that hit L1/L2).
+//
+// Mapping.  D = A B has its column on the lane (l & 31) and its rows in the registers, 4 (l >> 5) + (r & 3) + 8 (r >> 2): the
+// columns are 32 CHANNELS of the bank, the rows are [chunk l >> 5][output k = r >> 1][re / im = r & 1] -- each lane ends up
+// with the eight complex first-stage outputs of a block for one channel and ONE OF TWO time chunks the wave works on.  From
+// there on a lane walks its (channel, chunk) through time exactly as in k_mix_dec_fused: y0 = pa acc (the oscillator at the
+// window's centre: exact phase every eighth block, rotations in between), then the three halfbands in TRANSPOSED form with
+// every running sum in registers.  One wave does all of it, so nothing is handed over and nothing waits: a workgroup is one
+// wave, the launch puts one (or a few) on every SIMD, and the matrix pipe works on block o + 1 while the vector pipe runs the
+// halfbands of block o (the block's code places one matrix instruction between two halfband stages).  The running sums shift
+// by renaming: every one of them is written in every block, so the compiler writes it to its next place (no register moves).
+//
+// Chunks, warm-up and histories are k_mix_dec_fused's (same FusedDecGeom, same stage-0 history rows, same raw-input tail and
+// mixed-sample history left for the other routes), so a call may take any of the three routes.  What a call LEAVES (its last HY
+// first-stage outputs, the raw tail, the mixed-sample history) is the work of a few extra waves of the same launch that
+// recompute those 22 blocks' first stage and nothing else: the main waves carry no stores besides their results (a store in
+// front of a fetch makes the wait for the fetch a wait for the store -- one counter, in order).
+// Workgroup -> (chunk pair, channel group): consecutive workgroup ids are dealt to the eight XCDs round-robin, so the id's low
+// three bits select the chunk pair's residue and all channel groups of one stretch of the stream run on ONE XCD: the shared
+// stream is fetched once into one L2 instead of once into each (k_mix_dec_fused: 21.9 MB read for a 4.2 MB stream).
+#pragma once
+#include "kernels_fused_dec.h"
+
+namespace pg {
+
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+template <int NP>
+struct BankDecParams {
+    long long n_out;          // final outputs per channel in this call
+    long long out_pitch;      // float2 per row of `out`
+    long long y0_pitch;       // row pitch of the stage-0 history (float2)
+    long long n_in;           // input samples of this call = S * 8 * n_out
+    int S;                    // input samples per first-stage output
+    int L;                    // final outputs per chunk (multiple of 16)
+    int n_chan, n_chunks, n_groups;  // n_groups = ceil(n_chan / 32)
+    int hist_pitch;           // mixed-history row pitch (kMaxTaps)
+    int xh;                   // depth of the raw-input tail x_hist (samples in front of the call)
+    int min_off, max_off;     // smallest / largest sample offset of the front's window relative to S j
+    float a_inf, gain;        // oscillator amplitude, gain on the final output (the first stage's own gain is 1 in such a chain)
+    double ctr1;              // the window's centre + 1 relative to S j: pa(j) = amp e^{j 2 pi (phase0 + (S j + ctr1) inc)}
+    int oa[NP], ob[NP];       // pair p = samples S j + oa[p], S j + ob[p]
+    float g[NP];              // its tap (a centre tap as a pair with itself and half the weight)
+    float e[NP];              // (oa - ob) / 2
+    const float2 *state_in;   // [n_chan][N1 + N2 + N3] the halfbands' running sums where the previous call ended (nullptr: that call took another route:
+                              // chunk 0 then warms up from the first-stage history)
+    float2 *state_out;        // the same for the next call
+    int hist_split, pad2_;    // history waves per channel group
+    unsigned long long *clk;  // diagnosis (PEBBLEGPU_BANK_CLK): per wave {shader clocks, 100 MHz ticks, blocks} of its block loop; nullptr otherwise
+};
+
+// grid: n_main = 8 * ceil(pairs / 8) * ceil(n_groups / 4) workgroups of four INDEPENDENT waves (four channel groups of one chunk
+// pair; pairs = ceil(n_chunks / 2)), then ceil(n_groups / 4) workgroups of history waves.  (Single-wave workgroups were measured
+// first: the dispatcher put all four of a CU on one SIMD -- 1900 clocks per block instead of 1250; the four waves of one workgroup
+// go to the four SIMDs.)
+template <int NP, int T1, int T2, int T3, int DBG = 0>
+static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, const ChanOsc *__restrict__ osc,
+                                                               OscDynInline dyn, const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
+                                                               const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,
+                                                               float2 *__restrict__ mixed_hist_out, BankDecParams<NP> P)
+{
+    using G = FusedDecGeom<T1, T2, T3>;
+    constexpr int H1 = (T1 + 1) / 2, H2 = (T2 + 1) / 2, H3 = (T3 + 1) / 2;
+    constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY, WARM = G::warm;
+    constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
+    constexpr int REFRESH = 16;  // blocks between two exact oscillator phases (rotations in between)
+    __shared__ float2 tiles[4][2][16 * 65];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pairs = (P.n_chunks + 1) >> 1;
+    const int gq = (P.n_groups + 3) >> 2;
+    const int n_main = 8 * ((pairs + 7) >> 3) * gq;
+    const bool hist_wave = (int)blockIdx.x >= n_main;  // (uniform)
+    const int wq = blockIdx.x >> 3;
+    const int hq = hist_wave ? (int)blockIdx.x - n_main : 0;  // history workgroups: [channel-group quad][part]
+    const int hpart = hq % P.hist_split;
+    const int pair = hist_wave ? 0 : (wq / gq) * 8 + (blockIdx.x & 7);
+    const int grp = hist_wave ? (hq / P.hist_split) * 4 + wv : (wq % gq) * 4 + wv;
+    if (pair >= pairs || grp >= P.n_groups) return;  // wave-uniform (no workgroup barrier anywhere below)
+
+    // ---- D side: this lane's channel and chunk ----
+    const int S = P.S, L = P.L;
+    const int ch_raw = grp * 32 + (lane & 31), chunk_raw = 2 * pair + (lane >> 5);
+    const int c = ch_raw < P.n_chan ? ch_raw : P.n_chan - 1;
+    const int chunk = chunk_raw < P.n_chunks ? chunk_raw : P.n_chunks - 1;
+    const long long o0 = (long long)chunk * L;
+    const long long len0 = 8 * P.n_out;
+    const float2 *yh = y0_hist + (long long)c * P.y0_pitch;
+
+    const ChanOsc *oc = &osc[c];
+    const double inc = oc->inc;
+    double phase0 = oc->phase0;
+    uint32_t mix_on = oc->mix_on;
+    if (dyn.use) {
+#pragma unroll
+        for (int k = 0; k < kOscInline; k++)
+            if (c == k) { phase0 = dyn.d[k].phase0; mix_on = dyn.d[k].mix_on; }
+    }
+    const bool mix = mix_on != 0;
+    const float amp = mix ? P.a_inf : 1.f;  // (first-stage outputs stay unscaled: they are the history the other routes share)
+
+    // ---- B operand: lane l holds B[k = l >> 5][column l & 31] of every pair's 2 x 32 slice: g_p cos / g_p sin of this lane's channel ----
+    const int kq = lane >> 5;
+    float bco[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const float2 e = mix ? cis_cycles((double)P.e[p] * inc) : make_float2(1.f, 0.f);
+        bco[p] = P.g[p] * (kq == 0 ? e.x : e.y);
+    }
+    v2f_t r1 = {1.f, 0.f}, r2 = r1, r4 = r1, r8 = r1;
+    if (mix) {
+        const float2 a = cis_cycles((double)S * inc), b = cis_cycles((double)(2 * S) * inc), d = cis_cycles((double)(4 * S) * inc),
+                     f = cis_cycles((double)(8 * S) * inc);
+        r1 = v2f_t{a.x, a.y}; r2 = v2f_t{b.x, b.y}; r4 = v2f_t{d.x, d.y}; r8 = v2f_t{f.x, f.y};
+    }
+    // the oscillator at the centres of a block's eight windows from the first one's
+    auto osc8 = [&](v2f_t p0, v2f_t (&pa)[8]) {
+        pa[0] = p0;
+        pa[1] = cmul_pk(r1, pa[0]);
+        pa[2] = cmul_pk(r2, pa[0]); pa[3] = cmul_pk(r2, pa[1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) pa[4 + k] = cmul_pk(r4, pa[k]);
+    };
+    auto osc_exact = [&](long long j0) {
+        const float2 e = mix ? cscale(cis_cycles(phase0 + ((double)S * (double)j0 + P.ctr1) * inc), amp) : make_float2(amp, 0.f);
+        return v2f_t{e.x, e.y};
+    };
+    // y0 = pa * D.  The first of a product's two instructions is the compiler's own, so it pads the matrix result's read hazard (it
+    // does not model what is inside an asm statement); the second takes the half negation as an operand modifier
+    auto first_stage_out = [&](const v16f_t &D, const v2f_t (&pa)[8], float2 (&y0)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const v2f_t d = {D[2 * k], D[2 * k + 1]};
+            const v2f_t t = d.yx * pa[k].yy;  // (d.y p.y, d.x p.y)
+            v2f_t y;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1]" : "=v"(y) : "v"(d), "v"(pa[k]), "v"(t));  // (d.x p.x - t.x, d.y p.x + t.y)
+            y0[k] = make_float2(y.x, y.y);
+        }
+    };
+
+    // ---- A side: lane l holds A[row l & 31][k = l >> 5]; row = [half (l >> 2) & 1][output ((l >> 1) & 1) + 2 ((l >> 3) & 3)][re / im l & 1] ----
+    const int iA = lane & 31, compA = iA & 1, kA = ((iA >> 1) & 1) + 2 * (iA >> 3), halfA = (iA >> 2) & 1;
+    // k = 0: s_p = xa + xb in this row's component; k = 1: r_p = j (xa - xb): re = xb.im - xa.im, im = xa.re - xb.re
+    const int compL = kq == 0 ? compA : 1 - compA;
+    const float ca = (kq == 1 && compA == 0) ? -1.f : 1.f, cb = (kq == 1 && compA == 1) ? -1.f : 1.f;
+    const float *inf = reinterpret_cast<const float *>(in);
+    const float *xhf = reinterpret_cast<const float *>(x_hist);
+    // Sample fetches.  A lane's two samples of a pair sit at one 32-bit byte offset `voff` (this lane's element of the window's first
+    // sample; 64 S bytes further per block) plus the pair's place in the window as the instruction's scalar offset: no address
+    // arithmetic in the loop.  The offset is clamped into the buffer: windows that reach in front of the call or past its end belong
+    // to outputs nobody uses (chunk 0's warm-up blocks take the previous call's first-stage history; the output one past the call's
+    // end) -- except the first o_safe blocks of the call proper, whose windows straddle the call's first sample: those go through
+    // the slow path that picks the previous call's raw tail (`straddles`).
+    const unsigned vmax = (unsigned)(8 * (P.n_in - 1 - (P.max_off - P.min_off)) + 4 * compL);  // the last window that ends inside the call
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(inf), 0, (int)(unsigned)(P.n_in * 8), 0x00020000);
+    const int o_safe = (int)(((P.min_off < 0 ? ((long long)(-P.min_off) + S - 1) / S : 0) + 14) / 8);  // S (8 o - 7) + min_off >= 0 from block o_safe on
+    float ld[2 * NP];
+    const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    if (hist_wave) {
+        // ------------------------------------------------------------------------------------------------------------------------
+        // What the call leaves: its last HY first-stage outputs (blocks n_out - 22 .. n_out, twelve per lane half), the raw-input
+        // tail, and for the two-kernel route the mixed-sample history m[n-10 .. n-1] (each with its exact phase)
+        // ------------------------------------------------------------------------------------------------------------------------
+        constexpr int HB = (HY / 8 + 2) / 2;  // blocks per half
+        const long long ohA = P.n_out - 2 * HB + 1 + (long long)halfA * HB, ohD = P.n_out - 2 * HB + 1 + (long long)(lane >> 5) * HB;
+        auto hfetch = [&](int i) {  // block i's samples (the window's first sample lies inside the call, or its outputs are not kept)
+            const long long sj = (long long)S * (8 * (ohA + i) - 7 + kA) + P.min_off;
+            long long v8 = 8 * sj + 4 * compL;
+            v8 = v8 < 0 ? 0 : v8;
+            const unsigned vc = (unsigned long long)v8 < (unsigned long long)vmax ? (unsigned)v8 : vmax;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                ld[2 * p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.oa[p] - P.min_off), 0));
+                ld[2 * p + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.ob[p] - P.min_off), 0));
+            }
+        };
+        const int per = (HB + P.hist_split - 1) / P.hist_split, i_lo = hpart * per, i_hi = i_lo + per < HB ? i_lo + per : HB;
+        if (i_lo < i_hi) hfetch(i_lo);
+        for (int i = i_lo; i < i_hi; i++) {
+            float av[NP];
+#pragma unroll
+            for (int p = 0; p < NP; p++) av[p] = __builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]);
+            hfetch(i + 1 < i_hi ? i + 1 : i);  // the next block's samples travel while this one is worked on
+            v16f_t acc = zero16;
+#pragma unroll
+            for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bco[p], acc, 0, 0, 0);
+            const long long j0 = 8 * (ohD + i) - 7;
+            v2f_t pa[8];
+            osc8(osc_exact(j0), pa);
+            float2 y0[8];
+            first_stage_out(acc, pa, y0);
+            if (ch_raw < P.n_chan) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const long long j = j0 + k;
+                    if (j >= len0 - HY && j < len0) y0_stage[(long long)c * HY + (j - (len0 - HY))] = y0[k];
+                }
+            }
+        }
+        if (grp == 0 && hpart == 0) {
+            for (int i = lane; i < P.xh; i += 64) {
+                const long long src = P.n_in - P.xh + i;
+                xh_out[i] = src >= 0 ? in[src] : x_hist[P.xh + src];
+            }
+        }
+        if (hpart == P.hist_split - 1 && ch_raw < P.n_chan && lane < 32 && mixed_hist_out != nullptr) {
+            float2 *hp = mixed_hist_out + (long long)c * P.hist_pitch;
+            float2 xv[10];
+#pragma unroll
+            for (int q = 0; q < 10; q++) xv[q] = in[P.n_in - 10 + q];
+            // (exact phase at the first of the ten, a rotation per sample from there: ten steps)
+            const float2 st = mix ? cis_cycles(inc) : make_float2(1.f, 0.f);
+            float2 ph = mix ? cscale(cis_cycles(phase0 + (double)(P.n_in - 9) * inc), P.a_inf) : make_float2(1.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                hp[q] = mix ? cmul(ph, xv[q]) : xv[q];
+                ph = cmul(st, ph);
+            }
+        }
+        return;
+    }
+
+    // ----------------------------------------------------------------------------------------------------------------------------
+    // main waves
+    // ----------------------------------------------------------------------------------------------------------------------------
+    float2 *tile0 = tiles[wv][0], *tile1 = tiles[wv][1];
+    const int nb = L + WARM;
+    int chunkA = 2 * pair + halfA;
+    if (chunkA >= P.n_chunks) chunkA = P.n_chunks - 1;
+    const long long oA_start = (long long)chunkA * L - WARM;
+    // (modulo 2^32: exact wherever it is used unclamped -- the host sends calls of 4 GiB or more down the other routes)
+    unsigned voff = (unsigned)(4 * (2LL * S * (8 * oA_start - 7 + kA) + compL + 2LL * P.min_off));
+    // (uniform) block `it` holds outputs whose windows straddle the call's first sample: chunk 0 at o = 0 .. o_safe - 1, and chunk 1
+    // when it is shorter than the warm-up (L = 16)
+    auto straddles = [&](int it) {
+        return pair == 0 && ((it >= WARM && it < WARM + o_safe) || (it >= WARM - L && it < WARM - L + o_safe));
+    };
+    // the two raw samples of pair p for block `it` of both chunks (block index relative to the chunks' first block); `voff` is that block's
+    auto fetch_pair = [&](int it, int p, auto edgec) {
+        if constexpr (!decltype(edgec)::value && (DBG & 1) != 0) return;  // (timing experiment: no sample fetches in the plain blocks)
+        bool slow = false;
+        if constexpr (decltype(edgec)::value) slow = straddles(it);
+        if (!slow) {
+            const unsigned vc = voff < vmax ? voff : vmax;
+            ld[2 * p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.oa[p] - P.min_off), 0));
+            ld[2 * p + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.ob[p] - P.min_off), 0));
+        } else {
+            const long long sj = (long long)S * (8 * (oA_start + it) - 7 + kA);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                long long i = sj + (q == 0 ? P.oa[p] : P.ob[p]);
+                i = i < P.n_in ? i : P.n_in - 1;
+                long long ih = (long long)P.xh + i;  // in front of the call: the previous call's tail (never used when older than that)
+                ih = ih > 0 ? ih : 0;
+                ld[2 * p + q] = i >= 0 ? inf[2 * i + compL] : xhf[2 * ih + compL];
+            }
+        }
+    };
+    v16f_t D;
+
+    float2 a1[N1], a2[N2], a3[N3];
+#pragma unroll
+    for (int i = 0; i < N1; i++) a1[i] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < N2; i++) a2[i] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < N3; i++) a3[i] = make_float2(0.f, 0.f);
+    auto bc = [](float h) { return make_float2(h, h); };
+    v2f_t pa_blk = {amp, 0.f};
+
+    // prologue: block 0 through the matrix pipe, block 1's samples on their way
+    {
+        v16f_t acc = zero16;
+#pragma unroll
+        for (int p = 0; p < NP; p++) fetch_pair(0, p, std::true_type{});
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]), bco[p], acc, 0, 0, 0);
+        D = acc;
+        voff += 64u * S;
+#pragma unroll
+        for (int p = 0; p < NP; p++) fetch_pair(1, p, std::true_type{});
+        voff += 64u * S;
+    }
+
+    // Results leave as whole 128-byte row segments, one store instruction per block: a block parks its 64 results in one of two LDS
+    // tiles [16 outputs][64 (channel, chunk) lanes] and stores one sixteenth of the tile the sixteen blocks before it filled (four
+    // lanes' rows x 16 outputs).  The lane part of the address never changes; the rest is the instruction's scalar offset.
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(unsigned)((unsigned long long)P.n_chan * (unsigned long long)P.out_pitch * 8ull), 0x00020000);
+    const unsigned ovoff = (unsigned)(8 * ((long long)(lane >> 4) * P.out_pitch + (lane & 15)));
+    const int ch_lim = P.n_chan - grp * 32;  // channels of this group that exist
+    // group g (four lanes' rows) of the tile whose first output is rel_b (relative to the chunks' first outputs)
+    // (every store is issued: the ones that must not land carry an out-of-range lane offset, which the buffer's range check
+    // drops -- the scalar offset takes no part in that check.  A store inside a branch would leave the compiler no static count of the
+    // memory operations in flight, and the wait for the next block's samples would become a wait for the store)
+    constexpr unsigned kNoStore = 0xFFFFFF00u;
+    auto store_group = [&](float2 v, int g, int rel_b, bool on) {
+        const int row0 = (4 * g) & 31, half = g >> 3;
+        const long long ob = (long long)(2 * pair + half) * L + rel_b;
+        const bool ok = on && 2 * pair + half < P.n_chunks && ob < P.n_out;  // (uniform)
+        const long long so = ok ? 8 * ((long long)(grp * 32 + row0) * P.out_pitch + ob) : 0;
+        const unsigned vo = ok && row0 + (int)(lane >> 4) < ch_lim ? ovoff : kNoStore;
+        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{v.x, v.y}, orsrc, vo, (int)(unsigned)so, 0);
+    };
+
+    // One block; `it` = its index in the chunk (0 = first warm-up block).  On entry D holds the block's matrix products and ld the raw
+    // samples of block it + 1.  EDGE: the variant for the blocks at the call's start (first-stage outputs in front of the call from the
+    // previous call's tail `yq`, requested a block ahead; the slow sample fetches of the straddling blocks); the plain variant is one
+    // straight run of code.
+    auto block = [&](int it, auto edgec, float2 (&yq)[8]) {
+        constexpr bool EDGE = decltype(edgec)::value;
+        const int rel = it - WARM;               // block o = o0 + rel = final output o
+        const long long o = o0 + rel;
+        const long long j0 = 8 * o - 7;          // its first-stage outputs j0 .. j0 + 7
+        // the oscillator at the centre of output j0's window: exact every REFRESH blocks, a constant rotation in between
+        if ((it & (REFRESH - 1)) == 0) pa_blk = osc_exact(j0);
+        else pa_blk = cmul_pk(r8, pa_blk);
+        v2f_t pa[8];
+        osc8(pa_blk, pa);
+        float2 y0[8];
+        first_stage_out(D, pa, y0);
+        // The matrix instructions of block it + 1 go BETWEEN the halfband stages of this block.  Nothing but data dependences keeps
+        // them there (the compiler sinks and hoists across everything else, and a wave issues in order: back to back, every
+        // dependent matrix instruction would hold the wave for its 64 cycles), so the order is spelled out as dependences through
+        // empty asm statements: a step's A operand "depends" on everything the stage in front of it wrote, and the inputs of the stage
+        // behind it "depend" on the step's accumulator.  Each pair's samples for block it + 2 are requested right where the
+        // registers they land in have been read.
+        v16f_t acc = zero16;
+        auto matrix_step = [&](int p, auto after) {
+            float l0 = ld[2 * p];
+            after(l0);
+            const float a = __builtin_fmaf(ca, l0, cb * ld[2 * p + 1]);
+            fetch_pair(it + 2, p, edgec);
+            if constexpr ((DBG & 2) != 0 && !EDGE) acc[p] += a * bco[p];  // (timing experiment: no matrix instructions in the plain blocks)
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bco[p], acc, 0, 0, 0);
+        };
+        auto behind_matrix = [&](float2 &x) { asm volatile("" : "+v"(x.x) : "v"(acc)); };
+        // (a front with more than four pairs -- a merged CIC3 in front of the hb11 -- issues the surplus first)
+#pragma unroll
+        for (int p = 0; p + 3 < NP; p++)
+            matrix_step(p, [&](float &l) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) asm volatile("" : "+v"(l) : "v"(y0[k].x));
+            });
+        if constexpr (EDGE) {
+            // first-stage outputs in front of the call's start come from the previous call's history: every warm-up block of a chunk
+            // that starts there when that call left no running sums (it took another route), else only block o = 0 (its outputs 0..6;
+            // output 7 is the call's first).  Then the request for the next block's
+            const bool h7 = o < 0, h = o <= 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) y0[k] = h ? yq[k] : y0[k];
+            y0[7] = h7 ? yq[7] : y0[7];
+#pragma unroll
+            for (int k = 0; k < 8; k++) yq[k] = yh[j0 + 8 + k];  // (the next block's)
+        }
+        // the tile read of this block's store goes first, the store last
+        const bool storing = rel >= 16;  // (uniform)
+        const float2 *tprev = ((rel >> 4) & 1) ? tile0 : tile1;
+        const float2 sv = tprev[(lane & 15) * 65 + 4 * (rel & 15) + (lane >> 4)];
+        // halfband 1 (transposed form, kernels_fused_dec.h): outputs 0..3 then 4..7 of the block
+        float2 y1[4];
+        auto hb1 = [&](int k) {
+            if (k & 1) {
+                const int b = (k - 1) / 2;
+#pragma unroll
+                for (int t = 0; t < H1; t++) {
+                    const float2 v = y0[k] * bc(hb_tap<T1>(T1 - 1 - 2 * t));
+                    a1[b + t] = t == H1 - 1 ? v : a1[b + t] + v;
+                }
+                y1[b] = a1[b];
+            } else {
+                a1[(k + PC1 - 1) / 2] = a1[(k + PC1 - 1) / 2] + y0[k] * bc(hb_tap<T1>(PC1));
+            }
+        };
+        auto after_a1 = [&](float &l) {
+#pragma unroll
+            for (int i = 0; i < N1; i++) asm volatile("" : "+v"(l) : "v"(a1[i].x));
+        };
+#pragma unroll
+        for (int k = 0; k < 4; k++) behind_matrix(y0[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) hb1(k);
+        if constexpr (NP >= 3) matrix_step(NP - 3, after_a1);
+#pragma unroll
+        for (int k = 4; k < 8; k++) behind_matrix(y0[k]);
+#pragma unroll
+        for (int k = 4; k < 8; k++) hb1(k);
+        if constexpr (NP >= 2) matrix_step(NP - 2, after_a1);
+        // halfband 2
+#pragma unroll
+        for (int b = 0; b < 4; b++) behind_matrix(y1[b]);
+        float2 y2[2];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (b & 1) {
+                const int b2 = (b - 1) / 2;
+#pragma unroll
+                for (int t = 0; t < H2; t++) {
+                    const float2 v = y1[b] * bc(hb_tap<T2>(T2 - 1 - 2 * t));
+                    a2[b2 + t] = t == H2 - 1 ? v : a2[b2 + t] + v;
+                }
+                y2[b2] = a2[b2];
+            } else {
+                a2[(b + PC2 - 1) / 2] = a2[(b + PC2 - 1) / 2] + y1[b] * bc(hb_tap<T2>(PC2));
+            }
+        }
+        matrix_step(NP - 1, [&](float &l) {
+#pragma unroll
+            for (int i = 0; i < N2; i++) asm volatile("" : "+v"(l) : "v"(a2[i].x));
+        });
+        behind_matrix(y2[0]);
+        behind_matrix(y2[1]);
+        D = acc;
+        voff += 64u * S;
+        // halfband 3
+        a3[(PC3 - 1) / 2] = a3[(PC3 - 1) / 2] + y2[0] * bc(hb_tap<T3>(PC3));
+#pragma unroll
+        for (int t = 0; t < H3; t++) {
+            const float2 v = y2[1] * bc(hb_tap<T3>(T3 - 1 - 2 * t));
+            a3[t] = t == H3 - 1 ? v : a3[t] + v;
+        }
+        const float2 y3 = a3[0];
+        // the sums still pending move up by 4 / 2 / 1 places (renamed, not moved: every one of them is written in every block)
+#pragma unroll
+        for (int i = 0; i + 4 < N1; i++) a1[i] = a1[i + 4];
+#pragma unroll
+        for (int i = 0; i + 2 < N2; i++) a2[i] = a2[i + 2];
+#pragma unroll
+        for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
+        if (rel >= 0) {  // (uniform)
+            float2 *tcur = ((rel >> 4) & 1) ? tile1 : tile0;
+            tcur[(rel & 15) * 65 + lane] = cscale(y3, P.gain);
+        }
+        store_group(sv, rel & 15, (rel & ~15) - 16, storing);
+    };
+
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    int it = 0;
+    float2 none[8];
+    if (pair == 0) {  // (uniform)
+        // Edge blocks: all blocks up to the last straddling one when the chunks warm up from the first-stage history; with the
+        // running sums restored, only the blocks around the restore -- the warm-up blocks in front run plain and what they leave in a
+        // chunk that starts at the call's start is overwritten
+        int e0 = 0, e_lo = WARM + 1 + o_safe;
+        if (e_lo > nb) e_lo = nb;
+        if (P.state_in != nullptr) {
+            e0 = (L < WARM ? WARM - L : WARM) - 2;  // (L = 16: chunk 1 starts in front of the call as well)
+            e0 = e0 < 0 ? 0 : e0;
+        }
+        for (; it < e0; it++) block(it, std::false_type{}, none);
+        float2 yq[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) yq[k] = yh[8 * (o0 - WARM + it) - 7 + k];
+        for (; it < e_lo; it++) {
+            if (P.state_in != nullptr && (it == WARM || it == WARM - L)) {
+                // the running sums where the previous call ended, in the lanes whose chunk reaches the call's start with this block
+                const float2 *st = P.state_in + (long long)c * (N1 + N2 + N3);
+                const bool mine = o0 - WARM + it == 0;
+#pragma unroll
+                for (int i = 0; i < N1; i++) { const float2 v = st[i]; a1[i] = mine ? v : a1[i]; }
+#pragma unroll
+                for (int i = 0; i < N2; i++) { const float2 v = st[N1 + i]; a2[i] = mine ? v : a2[i]; }
+#pragma unroll
+                for (int i = 0; i < N3; i++) { const float2 v = st[N1 + N2 + i]; a3[i] = mine ? v : a3[i]; }
+            }
+            block(it, std::true_type{}, yq);
+        }
+    }
+    for (; it < nb; it++) block(it, std::false_type{}, none);
+    // the running sums where this call ends, for the next call's chunk 0 (L divides n_out: the last chunk is a whole one)
+    if (P.state_out != nullptr && 2 * pair + 1 >= P.n_chunks - 1 && chunk_raw == P.n_chunks - 1 && ch_raw < P.n_chan) {
+        float2 *st = P.state_out + (long long)c * (N1 + N2 + N3);
+#pragma unroll
+        for (int i = 0; i < N1; i++) st[i] = a1[i];
+#pragma unroll
+        for (int i = 0; i < N2; i++) st[N1 + i] = a2[i];
+#pragma unroll
+        for (int i = 0; i < N3; i++) st[N1 + N2 + i] = a3[i];
+    }
+    // the last tile
+    {
+        wave_sync();
+        const float2 *tl = (((L - 1) >> 4) & 1) ? tile1 : tile0;
+        for (int g = 0; g < 16; g++) store_group(tl[(lane & 15) * 65 + 4 * g + (lane >> 4)], g, (L - 1) & ~15, true);
+    }
+    if (P.clk != nullptr && lane == 0) {
+        unsigned long long *w = P.clk + 4 * ((size_t)blockIdx.x * 4 + wv);
+        w[0] = __builtin_amdgcn_s_memtime() - clk0;
+        w[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        w[2] = (unsigned long long)nb;
+        w[3] = (unsigned long long)pair;
+    }
+}
+
+}  // namespace pg

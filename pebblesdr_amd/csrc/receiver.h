@@ -104,6 +104,14 @@ struct DecimCore {
     float2 *d_xhist[2] = {nullptr, nullptr};    // [16] raw input tail of the previous call, ping-pong with hist_parity
     float2 *d_y0stage = nullptr;                // [C][HY] the call's last first-stage outputs, copied into buf0's head-room by the tail refresh
     int fused_hy = 0, fused_L = 0;
+    // the same chain with its first stage on the matrix pipe, one wave per (32 channels, two chunks): k_mix_dec_mfma (kernels_bank_dec.h),
+    // the default route of such a bank; PEBBLEGPU_BANK_DEC=0 keeps the four-wave pipeline above
+    bool bank_mfma = false;
+    int bank_waves = 0;                          // target waves per SIMD of a launch (PEBBLEGPU_BANK_WAVES, default 1)
+    int xh_depth = 16;                           // samples of raw-input tail kept in d_xhist
+    float2 *d_bank_state[2] = {nullptr, nullptr};  // [C][38] the halfbands' running sums where the last k_mix_dec_mfma call ended (ping-pong)
+    int bank_state_parity = 0;
+    bool bank_state_valid = false;               // the previous call took that route (else the next one warms up from the first-stage history)
     int wide_taps = 0, wide_stride = 1;
     float *d_wide_taps = nullptr;
     HistBuf buf1;
