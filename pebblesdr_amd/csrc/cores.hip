@@ -682,7 +682,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             bp.clk = want_clk ? d_clk : nullptr;
             const char *edbg = getenv("PEBBLEGPU_BANK_DBG");  // timing experiments (wrong results)
             const int dbg = edbg ? atoi(edbg) : 0;
-            auto kern = dbg == 1 ? k_mix_dec_mfma<NP, 15, 19, 31, 1> : dbg == 2 ? k_mix_dec_mfma<NP, 15, 19, 31, 2> : dbg == 3 ? k_mix_dec_mfma<NP, 15, 19, 31, 3> : k_mix_dec_mfma<NP, 15, 19, 31, 0>;
+            auto kern = dbg == 1 ? k_mix_dec_mfma<NP, 15, 19, 31, 1> : dbg == 2 ? k_mix_dec_mfma<NP, 15, 19, 31, 2> : dbg == 3 ? k_mix_dec_mfma<NP, 15, 19, 31, 3> : dbg == 4 ? k_mix_dec_mfma<NP, 15, 19, 31, 4> : dbg == 8 ? k_mix_dec_mfma<NP, 15, 19, 31, 8> : dbg == 16 ? k_mix_dec_mfma<NP, 15, 19, 31, 16> : dbg == 31 ? k_mix_dec_mfma<NP, 15, 19, 31, 31> : k_mix_dec_mfma<NP, 15, 19, 31, 0>;
             launch(kern, dim3(n_wg), dim3(256), s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn,
                    (const float2 *)d_xhist[hist_parity], d_xhist[hist_parity ^ 1], (const float2 *)buf0.data(), d_y0stage, d_hist_mixed[hist_parity ^ 1], bp);
             PG_HIP(hipGetLastError());

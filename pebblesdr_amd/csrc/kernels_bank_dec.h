@@ -79,7 +79,6 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
     constexpr int H1 = (T1 + 1) / 2, H2 = (T2 + 1) / 2, H3 = (T3 + 1) / 2;
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY, WARM = G::warm;
     constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
-    constexpr int REFRESH = 16;  // blocks between two exact oscillator phases (rotations in between)
     __shared__ float2 tiles[4][2][16 * 65];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,13 +128,20 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
                      f = cis_cycles((double)(8 * S) * inc);
         r1 = v2f_t{a.x, a.y}; r2 = v2f_t{b.x, b.y}; r4 = v2f_t{d.x, d.y}; r8 = v2f_t{f.x, f.y};
     }
+    // c * x as ONE asm statement (between two statements the compiler pads a wait state: an issue slot each, and a lone wave pays
+    // every slot)
+    auto cmul2 = [](v2f_t cc, v2f_t x) {
+        v2f_t r;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "=&v"(r) : "v"(cc), "v"(x));
+        return r;
+    };
     // the oscillator at the centres of a block's eight windows from the first one's
     auto osc8 = [&](v2f_t p0, v2f_t (&pa)[8]) {
         pa[0] = p0;
-        pa[1] = cmul_pk(r1, pa[0]);
-        pa[2] = cmul_pk(r2, pa[0]); pa[3] = cmul_pk(r2, pa[1]);
+        pa[1] = cmul2(r1, pa[0]);
+        pa[2] = cmul2(r2, pa[0]); pa[3] = cmul2(r2, pa[1]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) pa[4 + k] = cmul_pk(r4, pa[k]);
+        for (int k = 0; k < 4; k++) pa[4 + k] = cmul2(r4, pa[k]);
     };
     auto osc_exact = [&](long long j0) {
         const float2 e = mix ? cscale(cis_cycles(phase0 + ((double)S * (double)j0 + P.ctr1) * inc), amp) : make_float2(amp, 0.f);
@@ -240,7 +246,6 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
     // ----------------------------------------------------------------------------------------------------------------------------
     // main waves
     // ----------------------------------------------------------------------------------------------------------------------------
-    float2 *tile0 = tiles[wv][0], *tile1 = tiles[wv][1];
     const int nb = L + WARM;
     int chunkA = 2 * pair + halfA;
     if (chunkA >= P.n_chunks) chunkA = P.n_chunks - 1;
@@ -283,7 +288,6 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
 #pragma unroll
     for (int i = 0; i < N3; i++) a3[i] = make_float2(0.f, 0.f);
     auto bc = [](float h) { return make_float2(h, h); };
-    v2f_t pa_blk = {amp, 0.f};
 
     // prologue: block 0 through the matrix pipe, block 1's samples on their way
     {
@@ -300,24 +304,53 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
     }
 
     // Results leave as whole 128-byte row segments, one store instruction per block: a block parks its 64 results in one of two LDS
-    // tiles [16 outputs][64 (channel, chunk) lanes] and stores one sixteenth of the tile the sixteen blocks before it filled (four
-    // lanes' rows x 16 outputs).  The lane part of the address never changes; the rest is the instruction's scalar offset.
+    // tiles [16 outputs][64 (channel, chunk) lanes] and stores one sixteenth of the tile the sixteen blocks before it filled: two
+    // channels' rows x both chunks x 16 outputs (lane = [chunk][row][output]).  The lane part of the address never changes, the rest
+    // is the instruction's scalar offset, and everything that moves from block to block is a running value (one add each): every
+    // instruction of any kind is an issue slot of a wave that has its SIMD to itself.
+    // (Every store is issued: the ones that must not land carry an out-of-range lane offset, which the buffer's range check drops --
+    // the scalar offset takes no part in that check.  A store inside a branch would leave the compiler no static count of the memory
+    // operations in flight, and the wait for the next block's samples would become a wait for the store.)
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(unsigned)((unsigned long long)P.n_chan * (unsigned long long)P.out_pitch * 8ull), 0x00020000);
-    const unsigned ovoff = (unsigned)(8 * ((long long)(lane >> 4) * P.out_pitch + (lane & 15)));
-    const int ch_lim = P.n_chan - grp * 32;  // channels of this group that exist
-    // group g (four lanes' rows) of the tile whose first output is rel_b (relative to the chunks' first outputs)
-    // (every store is issued: the ones that must not land carry an out-of-range lane offset, which the buffer's range check
-    // drops -- the scalar offset takes no part in that check.  A store inside a branch would leave the compiler no static count of the
-    // memory operations in flight, and the wait for the next block's samples would become a wait for the store)
     constexpr unsigned kNoStore = 0xFFFFFF00u;
-    auto store_group = [&](float2 v, int g, int rel_b, bool on) {
-        const int row0 = (4 * g) & 31, half = g >> 3;
-        const long long ob = (long long)(2 * pair + half) * L + rel_b;
-        const bool ok = on && 2 * pair + half < P.n_chunks && ob < P.n_out;  // (uniform)
-        const long long so = ok ? 8 * ((long long)(grp * 32 + row0) * P.out_pitch + ob) : 0;
-        const unsigned vo = ok && row0 + (int)(lane >> 4) < ch_lim ? ovoff : kNoStore;
-        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{v.x, v.y}, orsrc, vo, (int)(unsigned)so, 0);
+    const int st_t = lane & 15, st_row = (lane >> 4) & 1, st_half = lane >> 5;
+    const int ch_lim = P.n_chan - grp * 32;  // channels of this group that exist
+    const bool ragged = ch_lim < 32;         // (uniform)
+    // 32-bit offsets: the host keeps the result rows under 4 GiB
+    const unsigned ovoff = 2 * pair + st_half < P.n_chunks ? 8u * ((unsigned)st_row * (unsigned)P.out_pitch + (unsigned)st_half * (unsigned)L + (unsigned)st_t) : kNoStore;
+    const unsigned so_grp = 8u * (unsigned)(grp * 32) * (unsigned)P.out_pitch + 8u * (unsigned)(2 * pair) * (unsigned)L;
+    const unsigned so_row2 = 8u * 2u * (unsigned)P.out_pitch;
+    typedef v2f_t __attribute__((address_space(3))) lds_f2;  // (the native vector type: float2's operators do not exist in that address space)
+    const unsigned tb0 = (unsigned)(uintptr_t)(lds_f2 *)(v2f_t *)tiles[wv][0], tb1 = (unsigned)(uintptr_t)(lds_f2 *)(v2f_t *)tiles[wv][1];  // (LDS byte addresses)
+    const unsigned lds_wr0 = tb0 + 8u * lane, lds_wr1 = tb1 + 8u * lane;
+    const unsigned lds_rd0 = tb0 + 8u * (st_t * 65 + st_half * 32 + st_row), lds_rd1 = tb1 + 8u * (st_t * 65 + st_half * 32 + st_row);
+    auto lds_at = [](unsigned a) { return (lds_f2 *)(uintptr_t)a; };
+    // running values of a round of sixteen blocks (set by round_start)
+    unsigned twr = lds_wr0 + 8u * 65u * (unsigned)((-WARM) & 15), trd = lds_rd1, so_run = 0, vo_cur = kNoStore;
+    int row_run = st_row;  // (ragged groups) the channel row this lane stores next
+    v2f_t pa_blk = {amp, 0.f};
+    // the first block of a round (rel a multiple of 16): exact oscillator phase, the tiles change roles, the store's running offsets
+    auto round_start = [&](int rel, long long j0) {
+        pa_blk = osc_exact(j0);
+        const bool odd = ((rel >> 4) & 1) != 0;
+        twr = odd ? lds_wr1 : lds_wr0;
+        trd = odd ? lds_rd0 : lds_rd1;
+        so_run = so_grp + 8u * (unsigned)(rel - 16);
+        vo_cur = rel >= 16 ? ovoff : kNoStore;
+        row_run = st_row;
+    };
+    // the block's result into the tile being filled; one sixteenth of the other tile to memory
+    auto park_and_store = [&](float2 y, float2 sv) {
+        *lds_at(twr) = v2f_t{y.x, y.y};
+        twr += 8u * 65u;
+        unsigned vo = vo_cur;
+        if (ragged) {
+            vo = row_run < ch_lim ? vo : kNoStore;
+            row_run += 2;
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, (int)so_run, 0);
+        so_run += so_row2;
     };
 
     // One block; `it` = its index in the chunk (0 = first warm-up block).  On entry D holds the block's matrix products and ld the raw
@@ -329,27 +362,35 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
         const int rel = it - WARM;               // block o = o0 + rel = final output o
         const long long o = o0 + rel;
         const long long j0 = 8 * o - 7;          // its first-stage outputs j0 .. j0 + 7
-        // the oscillator at the centre of output j0's window: exact every REFRESH blocks, a constant rotation in between
-        if ((it & (REFRESH - 1)) == 0) pa_blk = osc_exact(j0);
-        else pa_blk = cmul_pk(r8, pa_blk);
+        // the oscillator at the centre of output j0's window: exact at every round's start, a constant rotation in between
+        if ((rel & 15) == 0) round_start(rel, j0);
+        else pa_blk = cmul2(r8, pa_blk);
         v2f_t pa[8];
-        osc8(pa_blk, pa);
         float2 y0[8];
-        first_stage_out(D, pa, y0);
+        if constexpr ((DBG & 16) != 0 && !EDGE) {  // (timing experiment: no oscillator, no product)
+#pragma unroll
+            for (int k = 0; k < 8; k++) y0[k] = make_float2(D[2 * k] + pa_blk.x, D[2 * k + 1]);
+        } else {
+            osc8(pa_blk, pa);
+            first_stage_out(D, pa, y0);
+        }
         // The matrix instructions of block it + 1 go BETWEEN the halfband stages of this block.  Nothing but data dependences keeps
         // them there (the compiler sinks and hoists across everything else, and a wave issues in order: back to back, every
         // dependent matrix instruction would hold the wave for its 64 cycles), so the order is spelled out as dependences through
         // empty asm statements: a step's A operand "depends" on everything the stage in front of it wrote, and the inputs of the stage
-        // behind it "depend" on the step's accumulator.  Each pair's samples for block it + 2 are requested right where the
-        // registers they land in have been read.
+        // behind it "depend" on the step's accumulator.
+        // the A values of block it + 1 at once, then all the requests for block it + 2 (a full block ahead of their use, one wait)
+        float av[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) av[p] = __builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) fetch_pair(it + 2, p, edgec);
+        voff += 64u * S;
         v16f_t acc = zero16;
         auto matrix_step = [&](int p, auto after) {
-            float l0 = ld[2 * p];
-            after(l0);
-            const float a = __builtin_fmaf(ca, l0, cb * ld[2 * p + 1]);
-            fetch_pair(it + 2, p, edgec);
-            if constexpr ((DBG & 2) != 0 && !EDGE) acc[p] += a * bco[p];  // (timing experiment: no matrix instructions in the plain blocks)
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bco[p], acc, 0, 0, 0);
+            after(av[p]);
+            if constexpr ((DBG & 2) != 0 && !EDGE) acc[p] += av[p] * bco[p];  // (timing experiment: no matrix instructions in the plain blocks)
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bco[p], acc, 0, 0, 0);
         };
         auto behind_matrix = [&](float2 &x) { asm volatile("" : "+v"(x.x) : "v"(acc)); };
         // (a front with more than four pairs -- a merged CIC3 in front of the hb11 -- issues the surplus first)
@@ -371,9 +412,12 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
             for (int k = 0; k < 8; k++) yq[k] = yh[j0 + 8 + k];  // (the next block's)
         }
         // the tile read of this block's store goes first, the store last
-        const bool storing = rel >= 16;  // (uniform)
-        const float2 *tprev = ((rel >> 4) & 1) ? tile0 : tile1;
-        const float2 sv = tprev[(lane & 15) * 65 + 4 * (rel & 15) + (lane >> 4)];
+        float2 sv = make_float2(0.f, 0.f);
+        if constexpr ((DBG & 8) == 0 || EDGE) {
+            const v2f_t t = *lds_at(trd);
+            sv = make_float2(t.x, t.y);
+            trd += 16u;
+        }
         // halfband 1 (transposed form, kernels_fused_dec.h): outputs 0..3 then 4..7 of the block
         float2 y1[4];
         auto hb1 = [&](int k) {
@@ -407,8 +451,9 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
 #pragma unroll
         for (int b = 0; b < 4; b++) behind_matrix(y1[b]);
         float2 y2[2];
+        if constexpr ((DBG & 4) != 0 && !EDGE) { y2[0] = y1[1]; y2[1] = y1[3]; }  // (timing experiment: no halfband 2)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (int b = 0; b < ((DBG & 4) != 0 && !EDGE ? 0 : 4); b++) {
             if (b & 1) {
                 const int b2 = (b - 1) / 2;
 #pragma unroll
@@ -428,7 +473,6 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
         behind_matrix(y2[0]);
         behind_matrix(y2[1]);
         D = acc;
-        voff += 64u * S;
         // halfband 3
         a3[(PC3 - 1) / 2] = a3[(PC3 - 1) / 2] + y2[0] * bc(hb_tap<T3>(PC3));
 #pragma unroll
@@ -444,13 +488,14 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
         for (int i = 0; i + 2 < N2; i++) a2[i] = a2[i + 2];
 #pragma unroll
         for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
-        if (rel >= 0) {  // (uniform)
-            float2 *tcur = ((rel >> 4) & 1) ? tile1 : tile0;
-            tcur[(rel & 15) * 65 + lane] = cscale(y3, P.gain);
+        if constexpr ((DBG & 8) == 0 || EDGE) {
+            park_and_store(cscale(y3, P.gain), sv);  // (the warm-up blocks' values land in rows that are rewritten before their tile is stored)
+        } else {
+            asm volatile("" :: "v"(y3.x), "v"(y3.y));  // (timing experiment: no tile, no store)
         }
-        store_group(sv, rel & 15, (rel & ~15) - 16, storing);
     };
 
+    pa_blk = osc_exact(8 * (o0 - WARM - 1) - 7);  // (the block's in front of block 0: every block but a round's first opens with one rotation)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     int it = 0;
     float2 none[8];
@@ -497,8 +542,22 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
     // the last tile
     {
         wave_sync();
-        const float2 *tl = (((L - 1) >> 4) & 1) ? tile1 : tile0;
-        for (int g = 0; g < 16; g++) store_group(tl[(lane & 15) * 65 + 4 * g + (lane >> 4)], g, (L - 1) & ~15, true);
+        const bool odd = (((L - 1) >> 4) & 1) != 0;
+        trd = odd ? lds_rd1 : lds_rd0;
+        so_run = so_grp + 8u * (unsigned)((L - 1) & ~15);
+        vo_cur = ovoff;
+        row_run = st_row;
+        for (int g = 0; g < 16; g++) {
+            const v2f_t sv = *lds_at(trd);
+            trd += 16u;
+            unsigned vo = vo_cur;
+            if (ragged) {
+                vo = row_run < ch_lim ? vo : kNoStore;
+                row_run += 2;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, (int)so_run, 0);
+            so_run += so_row2;
+        }
     }
     if (P.clk != nullptr && lane == 0) {
         unsigned long long *w = P.clk + 4 * ((size_t)blockIdx.x * 4 + wv);

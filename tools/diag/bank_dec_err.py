@@ -40,4 +40,6 @@ if __name__ == "__main__":
         e = np.abs(a[c] - b[c]).reshape(-1, 16).max(axis=1) / ref
         bad = np.nonzero(e > 1e-5)[0]
         print("channel", c, "blocks of 16 outputs:", len(e), "bad:", len(bad), "first/last bad:", bad[:3].tolist(), bad[-3:].tolist(), "max err", float(e.max()), "at", int(np.argmax(e)))
-        print("   log10 err per block from 120:", " ".join("%.0f" % np.log10(max(v, 1e-9)) for v in e[120:330]))
+        print("   log10 err per block from 120:", " ".join("%.0f" % np.log10(max(v, 1e-9)) for v in e[120:200]))
+        d = np.abs(a[c] - b[c])[2048 + 1024:].reshape(-1, 16) / ref   # by position inside a block of 16 outputs, past the first call and the filter's memory
+        print("   mean err by output position mod 16:", " ".join("%.1e" % v for v in d.mean(axis=0)))
