@@ -1167,6 +1167,39 @@ def test_full_size_configs2_256_ssb_channels(gpu_lib, oracle_mod):
         assert rel_rms(g[c], want) <= TOL
 
 
+@pytest.mark.parametrize("k", [8, 32])
+def test_bench_geometry_configs2_superframes_in_one_call(gpu_lib, oracle_mod, k):
+    """BASELINE configs[2] at the bench's own call geometry: 256 USB channels off one 2.048 Msps stream, 8 super-frames in one
+    call (bench.py's configs[2] step: one wave per SIMD, chunks of 64 outputs) and 32 (the batch sweep: two waves per SIMD,
+    chunks of 128), the bench's tuning plan.  Two such calls, so the second starts from the running sums, the first-stage
+    history and the raw tail the first one left (the first call of a stream sits in the oscillators' transient and takes the
+    two-kernel route).  Oracle on four channels over the whole stream; every frame of the last call is compared."""
+    import pebblesdr_amd as P
+    fs, n, C = 2048000, 2048, 256
+    fcs = [(c - C / 2.0) * (0.8 * fs / C) for c in range(C)]
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=k)
+    for c, fc in enumerate(fcs):
+        rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fc); rx.set_bandpass(c, 300, 3000)
+    sf = rx.superframe
+    check = (0, 37, 129, 255)
+    N = (1 + 2 * k) * sf
+    x = tones(fs, N, [(0.004, fcs[c] + 900.0 + 7.0 * c, 0.3 * c) for c in check] + [(0.002, fcs[c] + 1500.0, 0.1 * c) for c in range(3, C, 17)]) + lcg_noise(N, 5, 1e-3)
+    g = [rx.process(x[:sf])[0]]
+    names = [rx.kernel_name(2)]
+    for i in range(2):
+        g.append(rx.process(x[sf + i * k * sf:sf + (i + 1) * k * sf])[0])
+        names.append(rx.kernel_name(2))
+    assert names[1] in ("k_mix_dec_mfma", "k_mix_dec_fused") and names[2] == names[1]
+    g = np.concatenate(g, axis=1)
+    for c in check:
+        r = oracle_mod.Receiver(fs, n, 0)
+        r.set_mode(oracle_mod.USB); r.set_mixer(fcs[c]); r.set_filter(300, 3000)
+        want = np.concatenate([r.process(x[f * n:(f + 1) * n], want_spectrum=False)[0] for f in range(N // n)])
+        assert want.shape == g[c].shape
+        for f in range(g[c].shape[0] // 2048):
+            assert rel_rms(g[c][f * 2048:(f + 1) * 2048], want[f * 2048:(f + 1) * 2048]) <= TOL, (c, f)
+
+
 def test_full_size_configs3_512_channel_shard(gpu_lib, oracle_mod):
     """BASELINE configs[3], one GPU's shard at size: a 100 Msps stream, 512 AM/USB channels, one super-frame (4.2 M input
     samples, D = 2048).  Sixteen channels carry a signal; oracle (mixer + decimator + band-pass [+ AM]) on three of them,
