@@ -341,6 +341,191 @@ static size_t mixdec_lds_bytes(const FirTaps &t)
     return (size_t)(span + span / t.stride + 2) * sizeof(float2);
 }
 
+// ---- k_mix_dec_mfma's instantiations: fronts (4 pairs: hb11 x S; 12: a merged CIC3 in front of it) x the halfband triples the reference's ladder
+// puts behind them between 1 and 200 Msps (decimator.cpp:64-149) ----
+struct BankVariant {
+    int np, t1, t2, t3, hy, nstate, minw;
+    void *kern;
+};
+template <int NP, int T1, int T2, int T3, int MINW>
+static BankVariant bank_variant_of()
+{
+    using G = FusedDecGeom<T1, T2, T3>;
+    return BankVariant{NP, T1, T2, T3, G::HY, G::N1 + G::N2 + G::N3, MINW, (void *)k_mix_dec_mfma<NP, T1, T2, T3, 0, MINW>};
+}
+static const std::vector<BankVariant> &bank_variants()
+{
+    static const std::vector<BankVariant> v = {
+        bank_variant_of<4, 15, 19, 31, 2>(),  bank_variant_of<4, 15, 23, 43, 2>(),  bank_variant_of<4, 15, 23, 47, 2>(),  bank_variant_of<4, 15, 19, 35, 2>(),
+        bank_variant_of<4, 15, 27, 59, 1>(),  bank_variant_of<4, 19, 27, 59, 1>(),
+        bank_variant_of<12, 15, 23, 47, 2>(), bank_variant_of<12, 15, 19, 35, 2>(), bank_variant_of<12, 15, 27, 59, 1>(),
+    };
+    return v;
+}
+bool bank_variant(int np, int t1, int t2, int t3, int *hy, int *nstate, int *minw)
+{
+    for (const BankVariant &b : bank_variants())
+        if (b.np == np && b.t1 == t1 && b.t2 == t2 && b.t3 == t3) {
+            *hy = b.hy; *nstate = b.nstate; *minw = b.minw;
+            return true;
+        }
+    return false;
+}
+
+template <int NP>
+static int launch_bank(void *kern, unsigned n_wg, hipStream_t s, const float2 *d_in, float2 *out, const ChanOsc *osc, const OscDynInline &dyn, const float2 *xh,
+                       float2 *xh_out, const float2 *y0h, float2 *y0s, float2 *mixed, const BankDecParams<NP> &bp)
+{
+    using K = void (*)(const float2 *, float2 *, const ChanOsc *, OscDynInline, const float2 *, float2 *, const float2 *, float2 *, float2 *, BankDecParams<NP>);
+    launch(reinterpret_cast<K>(kern), dim3(n_wg), dim3(256), s, d_in, out, osc, dyn, xh, xh_out, y0h, y0s, mixed, bp);
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
+// the call's decimator as one launch of k_mix_dec_mfma (the caller has checked the sizes)
+int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, const OscBank &osc, bool had_state)
+{
+    const bool cic = fused_front;
+    const HistBuf &y0b = cic ? buf1 : buf0;
+    const int np = cic ? 12 : 4;
+    const BankVariant *bv = nullptr;
+    for (const BankVariant &b : bank_variants())
+        if (b.np == np && b.t1 == casc.ntaps[0] && b.t2 == casc.ntaps[1] && b.t3 == casc.ntaps[2]) bv = &b;
+    if (!bv) return fail(PEBBLEGPU_E_UNSUPPORTED, "no k_mix_dec_mfma instance for this chain");
+    const long long g32 = cdiv(C, 32);
+    const int warm = (bv->hy - 8) / 8;
+    // One wave per SIMD pays the fewest warm-up blocks; two overlap what a lone wave leaves idle (measured on hb11 x 4, 15/19/31: 1200
+    // clocks per block alone, 2075 for each of two) -- worth it once a chunk is long against its warm-up: from 128 outputs per chunk on
+    int waves = bank_waves;
+    if (waves == 0) waves = cdiv(len_out, 2 * std::max(1LL, 1024LL / g32)) >= 128 ? 2 : 1;
+    if (waves > bv->minw) waves = bv->minw;  // (the instances with the longest halfbands need more than half a SIMD's registers)
+    long long pairs_target = 1024LL * waves / g32;
+    if (pairs_target < 1) pairs_target = 1;
+    // a power of two (it divides the call's 2048 k outputs: the last chunk is a whole one), the nearest to the target above
+    long long L = 16;
+    if (fused_L > 0) {
+        while (L * 2 <= fused_L) L *= 2;
+    } else {
+        const long long want = cdiv(len_out, 2 * pairs_target);
+        while (L < want && L < 2048) L *= 2;
+    }
+    while (len_out % L != 0 && L > 16) L /= 2;
+    while (2 * L <= warm) L *= 2;  // (only the first two chunks may reach in front of the call's start)
+    const int S0 = first.stride, Sfs = cic ? S0 * wide_stride : S0;  // input samples per first-stage (hb11) output
+    const long long pairs = cdiv(cdiv(len_out, L), 2);
+    const int hist_split = 4;
+    const unsigned n_wg = (unsigned)(8 * cdiv(pairs, 8) * cdiv(g32, 4) + cdiv(g32, 4) * hist_split);  // main workgroups, then the history waves'
+    static unsigned long long *d_clk = nullptr;  // diagnosis only: PEBBLEGPU_BANK_CLK=1 prints the waves' clock counts of every such launch
+    static size_t clk_cap = 0;
+    const char *eclk = getenv("PEBBLEGPU_BANK_CLK");
+    const bool want_clk = eclk && eclk[0] == '1';
+    if (want_clk && clk_cap < (size_t)n_wg * 16) {
+        if (d_clk) (void)hipFree(d_clk);
+        PG_HIP(hipMalloc((void **)&d_clk, sizeof(unsigned long long) * n_wg * 16));
+        clk_cap = (size_t)n_wg * 16;
+    }
+    if (want_clk) PG_HIP(hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * n_wg * 16, s));
+    auto common = [&](auto &bp) {
+        bp.n_out = len_out;
+        bp.out_pitch = fin.pitch;
+        bp.y0_pitch = y0b.pitch;
+        bp.n_in = n;
+        bp.S = Sfs;
+        bp.L = (int)L;
+        bp.n_chan = (int)C;
+        bp.n_chunks = (int)cdiv(len_out, L);
+        bp.n_groups = (int)g32;
+        bp.hist_pitch = kMaxTaps;
+        bp.xh = xh_depth;
+        bp.a_inf = osc.a_inf;
+        bp.gain = casc.gain;  // (the first stage's own gain is 1 in a chain of several stages)
+        bp.hist_split = hist_split;
+        bp.cic_s0 = cic ? S0 : 0;
+        bp.state_in = had_state ? d_bank_state[bank_state_parity] : nullptr;
+        bp.state_out = d_bank_state[bank_state_parity ^ 1];
+        bp.clk = want_clk ? d_clk : nullptr;
+    };
+    const float2 *xh = d_xhist[hist_parity];
+    float2 *xh_out = d_xhist[hist_parity ^ 1], *mixed = d_hist_mixed[hist_parity ^ 1];
+    if (!cic) {
+        BankDecParams<4> bp;
+        memset(&bp, 0, sizeof(bp));
+        common(bp);
+        bp.min_off = -10;
+        bp.max_off = 0;
+        bp.ctr1 = -4.0;  // the hb11's centre tap sits on sample S j - 5; the oscillator of sample i is e^{j 2 pi (phase0 + (i + 1) inc)}
+        static const int kE[4] = {0, 1, 3, 5};
+        for (int p = 0; p < 4; p++) {
+            bp.oa[p] = -5 + kE[p];
+            bp.ob[p] = -5 - kE[p];
+            bp.e[p] = (float)kE[p];
+            bp.g[p] = p == 0 ? 0.5f * bank_taps.h[5] : bank_taps.h[5 + kE[p]];
+        }
+        void *kern = bv->kern;
+        const char *edbg = getenv("PEBBLEGPU_BANK_DBG");  // timing experiments on the configs[2] instance (wrong results)
+        const int dbg = edbg ? atoi(edbg) : 0;
+        if (dbg && bv->t1 == 15 && bv->t2 == 19 && bv->t3 == 31)
+            kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 2> : dbg == 3 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 3>
+                 : dbg == 4 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 4> : dbg == 8 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 16>
+                 : dbg == 31 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 31> : dbg == 100 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 0, 1> : kern;
+        if (int rc = launch_bank<4>(kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, (const float2 *)y0b.data(), d_y0stage, mixed, bp)) return rc;
+    } else {
+        // CIC3 at stride S0 in the reference's merged form (decimator.cpp:719-737: output k = .125 (od_k + ev_{k-1} + 3 (od_{k-1} + ev_k)) of the
+        // sample pairs (ev, od)_P = x[S0 P], x[S0 P + 1]) under the hb11 at stride 16: relative to sample S j, pair q = -11 .. 0 carries
+        // We[q] = (3 h[q+10] + h[q+11]) / 8 on its even and Wo[q] = (h[q+10] + 3 h[q+11]) / 8 on its odd sample; the response is symmetric about
+        // (-11 S0 + 1) / 2 (We[q] = Wo[-11-q]), which makes twelve (later, earlier) sample pairs with one weight each
+        BankDecParams<12> bp;
+        memset(&bp, 0, sizeof(bp));
+        common(bp);
+        bp.min_off = -11 * S0;
+        bp.max_off = 1;
+        bp.ctr1 = 0.5 * (-11.0 * S0 + 1.0) + 1.0;
+        auto h = [&](int d) { return d >= 0 && d <= 10 ? wide_fir.h[d] : 0.f; };
+        for (int i = 0; i < 6; i++) {
+            const int q = -11 + i;
+            bp.oa[2 * i] = S0 * (-11 - q) + 1;  bp.ob[2 * i] = S0 * q;          bp.g[2 * i] = (3.f * h(q + 10) + h(q + 11)) * 0.125f;
+            bp.oa[2 * i + 1] = S0 * (-11 - q);  bp.ob[2 * i + 1] = S0 * q + 1;  bp.g[2 * i + 1] = (h(q + 10) + 3.f * h(q + 11)) * 0.125f;
+        }
+        for (int p = 0; p < 12; p++) bp.e[p] = 0.5f * (float)(bp.oa[p] - bp.ob[p]);
+        if (int rc = launch_bank<12>(bv->kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, (const float2 *)y0b.data(), d_y0stage, mixed, bp)) return rc;
+    }
+    if (want_clk) {
+        std::vector<unsigned long long> h((size_t)n_wg * 16);
+        PG_HIP(hipStreamSynchronize(s));
+        PG_HIP(hipMemcpy(h.data(), d_clk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+        std::vector<double> per, ghz;
+        std::vector<std::pair<double, size_t>> slow;
+        double mx = 0;
+        for (size_t w = 0; w < (size_t)n_wg * 4; w++)
+            if (h[4 * w + 2]) {
+                per.push_back((double)h[4 * w] / (double)h[4 * w + 2]);
+                ghz.push_back((double)h[4 * w] / ((double)h[4 * w + 1] * 10.0));
+                slow.push_back({per.back(), w});
+                if ((double)h[4 * w + 1] > mx) mx = (double)h[4 * w + 1];
+            }
+        std::sort(per.begin(), per.end());
+        std::sort(ghz.begin(), ghz.end());
+        std::sort(slow.begin(), slow.end());
+        if (!per.empty()) {
+            fprintf(stderr, "k_mix_dec_mfma: %zu waves, L %d, clocks per block min %.0f median %.0f max %.0f; shader clock median %.2f GHz; longest wave %.1f us\n", per.size(),
+                    (int)L, per.front(), per[per.size() / 2], per.back(), ghz[ghz.size() / 2], mx / 100.0);
+            fprintf(stderr, "   slowest (clocks per block : workgroup.wave pair):");
+            for (size_t i = slow.size() > 12 ? slow.size() - 12 : 0; i < slow.size(); i++)
+                fprintf(stderr, " %.0f:%zu.%zu p%llu", slow[i].first, slow[i].second / 4, slow[i].second % 4, h[4 * slow[i].second + 3]);
+            size_t over = 0;
+            for (double v : per) over += v > 1.25 * per[per.size() / 2];
+            fprintf(stderr, "\n   waves more than 25 %% over the median: %zu\n", over);
+        }
+    }
+    hist_parity ^= 1;
+    bank_state_parity ^= 1;
+    bank_state_valid = true;
+    front_name = "k_mix_dec_mfma";
+    rest_name = "";
+    last_fused = true;
+    return 0;
+}
+
 int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain)
 {
     release();
@@ -411,35 +596,47 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
         }
         if (casc_lds_bytes > 150 * 1024) return fail(PEBBLEGPU_E_UNSUPPORTED, "decimation cascade does not fit LDS");
     }
-    // the whole decimator in one kernel: hb11 x S, then hb15, hb19, hb31 at stride 2 (k_mix_dec_fused<15, 19, 31>)
+    // the whole decimator in one kernel for banks off one shared stream: k_mix_dec_mfma for every chain of the form [cic3 x S0,] hb11 x S,
+    // three halfbands at stride 2 whose tap counts are in its table (bank_variant); k_mix_dec_fused<15, 19, 31>, its predecessor, for
+    // hb11 x S, hb15, hb19, hb31 (PEBBLEGPU_BANK_DEC=0)
     {
         using FG = FusedDecGeom<15, 19, 31>;
         const char *env = getenv("PEBBLEGPU_NO_FUSED_DEC");
-        fused_all = bank_front && C >= 16 && !wide && casc.nst == 3 && casc.ntaps[0] == 15 && casc.ntaps[1] == 19 && casc.ntaps[2] == 31 &&
-                    casc.stride[0] == 2 && casc.stride[1] == 2 && casc.stride[2] == 2 && first.stride <= 16 && !(env && env[0] == '1');
-        if (fused_all) {
-            fused_hy = FG::HY;
-            if (halo0 < fused_hy) halo0 = fused_hy;  // the stage-0 head-room doubles as the fused kernel's first-stage history
-            fused_p = new FusedDecParams();
-            memset(fused_p, 0, sizeof(*fused_p));
-            fused_p->S = first.stride;
-            fused_p->n_chan = (int)C;
-            fused_p->hist_pitch = kMaxTaps;
-            fused_p->gain0 = first.gain;
-            fused_p->gain = casc.gain;
+        const bool off = env && env[0] == '1';
+        const bool three2 = casc.nst == 3 && casc.stride[0] == 2 && casc.stride[1] == 2 && casc.stride[2] == 2;
+        const bool hb_front = bank_front && C >= 16 && !wide && first.stride <= 16;
+        const bool cic_front = fused_front && C >= 16 && wide_stride == 16;
+        fused_all = hb_front && three2 && casc.ntaps[0] == 15 && casc.ntaps[1] == 19 && casc.ntaps[2] == 31 && !off;
+        const char *eb = getenv("PEBBLEGPU_BANK_DEC");
+        bank_mfma = false;
+        if (three2 && (hb_front || cic_front) && !off && !(eb && eb[0] == '0'))
+            bank_mfma = bank_variant(cic_front ? 12 : 4, casc.ntaps[0], casc.ntaps[1], casc.ntaps[2], &fused_hy, &bank_nstate, &bank_minw);
+        if (fused_all && !bank_mfma) fused_hy = FG::HY;
+        if (fused_all || bank_mfma) {
+            if (halo0 < fused_hy) halo0 = fused_hy;  // the first-stage buffer's head-room doubles as these kernels' first-stage history
+            xh_depth = cic_front ? 512 : 16;         // raw samples in front of a call that its first windows reach (11 S0 + 1 with a CIC3 in front)
+            if (fused_all) {
+                fused_p = new FusedDecParams();
+                memset(fused_p, 0, sizeof(*fused_p));
+                fused_p->S = first.stride;
+                fused_p->n_chan = (int)C;
+                fused_p->hist_pitch = kMaxTaps;
+                fused_p->gain0 = first.gain;
+                fused_p->gain = casc.gain;
+            }
             for (int i = 0; i < 2; i++) {
-                PG_HIP(hipMalloc((void **)&d_xhist[i], sizeof(float2) * 16));
-                PG_HIP(hipMemset(d_xhist[i], 0, sizeof(float2) * 16));
+                PG_HIP(hipMalloc((void **)&d_xhist[i], sizeof(float2) * xh_depth));
+                PG_HIP(hipMemset(d_xhist[i], 0, sizeof(float2) * xh_depth));
             }
             PG_HIP(hipMalloc((void **)&d_y0stage, sizeof(float2) * (size_t)fused_hy * C));
-            const char *eb = getenv("PEBBLEGPU_BANK_DEC");
-            bank_mfma = !(eb && eb[0] == '0');
             const char *ew = getenv("PEBBLEGPU_BANK_WAVES");
             bank_waves = ew ? atoi(ew) : 0;  // 0: chosen per call
             if (bank_waves < 0 || bank_waves > 4) bank_waves = 0;
-            for (int i = 0; i < 2; i++) {
-                PG_HIP(hipMalloc((void **)&d_bank_state[i], sizeof(float2) * (size_t)(FG::N1 + FG::N2 + FG::N3) * C));
-                PG_HIP(hipMemset(d_bank_state[i], 0, sizeof(float2) * (size_t)(FG::N1 + FG::N2 + FG::N3) * C));
+            if (bank_mfma) {
+                for (int i = 0; i < 2; i++) {
+                    PG_HIP(hipMalloc((void **)&d_bank_state[i], sizeof(float2) * (size_t)bank_nstate * C));
+                    PG_HIP(hipMemset(d_bank_state[i], 0, sizeof(float2) * (size_t)bank_nstate * C));
+                }
             }
             bank_state_valid = false;
         }
@@ -613,8 +810,9 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     last_fused = false;
     const bool had_bank_state = bank_state_valid;
     bank_state_valid = false;  // (set again below when this call takes the matrix-pipe route)
-    if (fused_all && shared_input && !osc.any_transient()) {
-        if (len0 > buf0.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+    if ((fused_all || bank_mfma) && shared_input && !osc.any_transient()) {
+        const HistBuf &y0b = fused_front ? buf1 : buf0;  // the first-stage (hb11) outputs' buffer of the other route: its head-room is the history
+        if (n / ((long long)first.stride * (fused_front ? wide_stride : 1)) > y0b.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
         len_out = n / (long long)chain.total;
         const long long groups = cdiv(C, 64);
         if (!fused_L) {
@@ -624,109 +822,12 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             fused_L &= ~15;
         }
         if (bank_mfma && (unsigned long long)n * 8 < 0xFFF00000ull && (unsigned long long)C * (unsigned long long)fin.pitch * 8 < 0xFFF00000ull &&
-            len_out >= 64) {  // (its sample fetches and result stores carry 32-bit byte offsets)
-            // one wave per (32 channels, two chunks): chunk length for about bank_waves waves on each of the 1024 SIMDs
-            constexpr int NP = 4;
-            BankDecParams<NP> bp;
-            memset(&bp, 0, sizeof(bp));
-            const long long g32 = cdiv(C, 32);
-            // One wave per SIMD pays the fewest warm-up blocks; two overlap what a lone wave leaves idle (measured: 1200 clocks per block
-            // alone, 2075 for each of two) -- worth it once a chunk is long against its 21 warm-up blocks: from 128 outputs per chunk on
-            int waves = bank_waves;
-            if (waves == 0) waves = cdiv(len_out, 2 * std::max(1LL, 1024LL / g32)) >= 128 ? 2 : 1;
-            long long pairs_target = 1024LL * waves / g32;
-            if (pairs_target < 1) pairs_target = 1;
-            // a power of two (it divides the call's 2048 k outputs: the last chunk is a whole one), the nearest to the target above
-            long long L = 16;
-            if (fused_L > 0) {
-                while (L * 2 <= fused_L) L *= 2;
-            } else {
-                const long long want = cdiv(len_out, 2 * pairs_target);
-                while (L < want && L < 2048) L *= 2;
-            }
-            while (len_out % L != 0 && L > 16) L /= 2;
-            bp.n_out = len_out;
-            bp.out_pitch = fin.pitch;
-            bp.y0_pitch = buf0.pitch;
-            bp.n_in = n;
-            bp.S = first.stride;
-            bp.L = (int)L;
-            bp.n_chan = (int)C;
-            bp.n_chunks = (int)cdiv(len_out, L);
-            bp.n_groups = (int)g32;
-            bp.hist_pitch = kMaxTaps;
-            bp.xh = xh_depth;
-            bp.min_off = -10;
-            bp.max_off = 0;
-            bp.a_inf = osc.a_inf;
-            bp.gain = first.gain * casc.gain;
-            bp.ctr1 = -4.0;  // the hb11's centre tap sits on sample S j - 5; the oscillator of sample i is e^{j 2 pi (phase0 + (i + 1) inc)}
-            static const int kE[NP] = {0, 1, 3, 5};
-            for (int p = 0; p < NP; p++) {
-                bp.oa[p] = -5 + kE[p];
-                bp.ob[p] = -5 - kE[p];
-                bp.e[p] = (float)kE[p];
-                bp.g[p] = p == 0 ? 0.5f * bank_taps.h[5] : bank_taps.h[5 + kE[p]];
-            }
-            const long long pairs = cdiv(bp.n_chunks, 2);
-            bp.hist_split = 4;
-            bp.state_in = had_bank_state ? d_bank_state[bank_state_parity] : nullptr;
-            bp.state_out = d_bank_state[bank_state_parity ^ 1];
-            const unsigned n_wg = (unsigned)(8 * cdiv(pairs, 8) * cdiv(g32, 4) + cdiv(g32, 4) * bp.hist_split);  // main workgroups, then the history waves'
-            static unsigned long long *d_clk = nullptr;  // diagnosis only: PEBBLEGPU_BANK_CLK=1 prints the waves' clock counts of every such launch
-            static size_t clk_cap = 0;
-            const char *eclk = getenv("PEBBLEGPU_BANK_CLK");
-            const bool want_clk = eclk && eclk[0] == '1';
-            if (want_clk && clk_cap < (size_t)n_wg * 16) {
-                if (d_clk) (void)hipFree(d_clk);
-                PG_HIP(hipMalloc((void **)&d_clk, sizeof(unsigned long long) * n_wg * 16));
-                clk_cap = (size_t)n_wg * 16;
-            }
-            if (want_clk) PG_HIP(hipMemsetAsync(d_clk, 0, sizeof(unsigned long long) * n_wg * 16, s));
-            bp.clk = want_clk ? d_clk : nullptr;
-            const char *edbg = getenv("PEBBLEGPU_BANK_DBG");  // timing experiments (wrong results)
-            const int dbg = edbg ? atoi(edbg) : 0;
-            auto kern = dbg == 1 ? k_mix_dec_mfma<NP, 15, 19, 31, 1> : dbg == 2 ? k_mix_dec_mfma<NP, 15, 19, 31, 2> : dbg == 3 ? k_mix_dec_mfma<NP, 15, 19, 31, 3> : dbg == 4 ? k_mix_dec_mfma<NP, 15, 19, 31, 4> : dbg == 8 ? k_mix_dec_mfma<NP, 15, 19, 31, 8> : dbg == 16 ? k_mix_dec_mfma<NP, 15, 19, 31, 16> : dbg == 31 ? k_mix_dec_mfma<NP, 15, 19, 31, 31> : k_mix_dec_mfma<NP, 15, 19, 31, 0>;
-            launch(kern, dim3(n_wg), dim3(256), s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn,
-                   (const float2 *)d_xhist[hist_parity], d_xhist[hist_parity ^ 1], (const float2 *)buf0.data(), d_y0stage, d_hist_mixed[hist_parity ^ 1], bp);
-            PG_HIP(hipGetLastError());
-            if (want_clk) {
-                std::vector<unsigned long long> h((size_t)n_wg * 16);
-                PG_HIP(hipStreamSynchronize(s));
-                PG_HIP(hipMemcpy(h.data(), d_clk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-                std::vector<double> per, ghz;
-                std::vector<std::pair<double, size_t>> slow;
-                double mx = 0;
-                for (size_t w = 0; w < (size_t)n_wg * 4; w++)
-                    if (h[4 * w + 2]) {
-                        per.push_back((double)h[4 * w] / (double)h[4 * w + 2]);
-                        ghz.push_back((double)h[4 * w] / ((double)h[4 * w + 1] * 10.0));
-                        slow.push_back({per.back(), w});
-                        if ((double)h[4 * w + 1] > mx) mx = (double)h[4 * w + 1];
-                    }
-                std::sort(per.begin(), per.end());
-                std::sort(ghz.begin(), ghz.end());
-                std::sort(slow.begin(), slow.end());
-                if (!per.empty()) {
-                    fprintf(stderr, "k_mix_dec_mfma: %zu waves, L %d, clocks per block min %.0f median %.0f max %.0f; shader clock median %.2f GHz; longest wave %.1f us\n", per.size(),
-                            bp.L, per.front(), per[per.size() / 2], per.back(), ghz[ghz.size() / 2], mx / 100.0);
-                    fprintf(stderr, "   slowest (clocks per block : workgroup.wave pair):");
-                    for (size_t i = slow.size() > 12 ? slow.size() - 12 : 0; i < slow.size(); i++)
-                        fprintf(stderr, " %.0f:%zu.%zu p%llu", slow[i].first, slow[i].second / 4, slow[i].second % 4, h[4 * slow[i].second + 3]);
-                    size_t over = 0;
-                    for (double v : per) over += v > 1.25 * per[per.size() / 2];
-                    fprintf(stderr, "\n   waves more than 25 %% over the median: %zu\n", over);
-                }
-            }
-            hist_parity ^= 1;
-            bank_state_parity ^= 1;
-            bank_state_valid = true;
-            front_name = "k_mix_dec_mfma";
-            rest_name = "";
-            last_fused = true;
+            len_out >= 64 && (reinterpret_cast<uintptr_t>(d_in) & 7) == 0) {  // (its sample fetches and result stores carry 32-bit byte offsets)
+            if (int rc = run_bank_mfma(s, d_in, n, osc, had_bank_state)) return rc;
             if (after_first) PG_HIP(hipEventRecord(after_first, s));
             return 0;
         }
+      if (fused_all) {
         long long L = fused_L > 0 ? fused_L : ((len_out * groups / 704 + 15) & ~15LL);  // ~700 four-wave workgroups (measured best on 256 CUs: 96 for configs[2]); every chunk pays a 21-block warm-up
         if (L < 32) L = 32;
         fused_p->n_out = len_out;
@@ -743,6 +844,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         last_fused = true;
         if (after_first) PG_HIP(hipEventRecord(after_first, s));
         return 0;
+      }
     }
     if (fused_front) {
         len1 = len0 / wide_stride;
@@ -822,8 +924,8 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
                    fin.pitch, len_out, casc);
     }
     PG_HIP(hipGetLastError());
-    if (fused_all && shared_input)  // the next call may take the fused route: it wants this call's raw tail (hist_parity already flipped)
-        PG_HIP(hipMemcpyAsync(d_xhist[hist_parity], d_in + (n - 16), sizeof(float2) * 16, hipMemcpyDeviceToDevice, s));
+    if ((fused_all || bank_mfma) && shared_input && n >= xh_depth)  // the next call may take a one-kernel route: it wants this call's raw tail (hist_parity already flipped)
+        PG_HIP(hipMemcpyAsync(d_xhist[hist_parity], d_in + (n - xh_depth), sizeof(float2) * xh_depth, hipMemcpyDeviceToDevice, s));
     if (fuse_window && n >= 2048 && shape_for_spectrum()) {  // the next call's decimator may run inside the display transform
         launch(k_window_tail, dim3(8), dim3(256), s, d_in, n, fuse_window, d_xtail_w[xtail_parity ^ 1], raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0});
         xtail_parity ^= 1;
@@ -834,7 +936,8 @@ void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
 {
     if (last_fused) {
         // the call's last first-stage outputs (staged by the kernel) become the stage-0 head-room, as if the buffer had been written
-        jobs.push_back(TailJob{d_y0stage, (long long)fused_hy, (long long)fused_hy, fused_hy, 0, buf0.base + (buf0.hist - fused_hy), buf0.pitch});
+        const HistBuf &y0b = fused_front ? buf1 : buf0;
+        jobs.push_back(TailJob{d_y0stage, (long long)fused_hy, (long long)fused_hy, fused_hy, 0, y0b.base + (y0b.hist - fused_hy), y0b.pitch});
         if (fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
         return;
     }

@@ -61,7 +61,9 @@ struct BankDecParams {
     const float2 *state_in;   // [n_chan][N1 + N2 + N3] the halfbands' running sums where the previous call ended (nullptr: that call took another route:
                               // chunk 0 then warms up from the first-stage history)
     float2 *state_out;        // the same for the next call
-    int hist_split, pad2_;    // history waves per channel group
+    int hist_split;           // history waves per channel group
+    int cic_s0;               // 0: the front is hb11 x S (the two-kernel route keeps ten mixed samples); else the merged CIC3's stride S0 in front of
+                              // the hb11 (that route keeps the call's last twelve mixed sample pairs S0 P, S0 P + 1)
     unsigned long long *clk;  // diagnosis (PEBBLEGPU_BANK_CLK): per wave {shader clocks, 100 MHz ticks, blocks} of its block loop; nullptr otherwise
 };
 
@@ -69,8 +71,8 @@ struct BankDecParams {
 // pair; pairs = ceil(n_chunks / 2)), then ceil(n_groups / 4) workgroups of history waves.  (Single-wave workgroups were measured
 // first: the dispatcher put all four of a CU on one SIMD -- 1900 clocks per block instead of 1250; the four waves of one workgroup
 // go to the four SIMDs.)
-template <int NP, int T1, int T2, int T3, int DBG = 0>
-static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, const ChanOsc *__restrict__ osc,
+template <int NP, int T1, int T2, int T3, int DBG = 0, int MINW = 2>
+static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, const ChanOsc *__restrict__ osc,
                                                                OscDynInline dyn, const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
                                                                const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,
                                                                float2 *__restrict__ mixed_hist_out, BankDecParams<NP> P)
@@ -228,16 +230,31 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
         }
         if (hpart == P.hist_split - 1 && ch_raw < P.n_chan && lane < 32 && mixed_hist_out != nullptr) {
             float2 *hp = mixed_hist_out + (long long)c * P.hist_pitch;
-            float2 xv[10];
+            if (P.cic_s0 == 0) {
+                float2 xv[10];
 #pragma unroll
-            for (int q = 0; q < 10; q++) xv[q] = in[P.n_in - 10 + q];
-            // (exact phase at the first of the ten, a rotation per sample from there: ten steps)
-            const float2 st = mix ? cis_cycles(inc) : make_float2(1.f, 0.f);
-            float2 ph = mix ? cscale(cis_cycles(phase0 + (double)(P.n_in - 9) * inc), P.a_inf) : make_float2(1.f, 0.f);
+                for (int q = 0; q < 10; q++) xv[q] = in[P.n_in - 10 + q];
+                // (exact phase at the first of the ten, a rotation per sample from there: ten steps)
+                const float2 st = mix ? cis_cycles(inc) : make_float2(1.f, 0.f);
+                float2 ph = mix ? cscale(cis_cycles(phase0 + (double)(P.n_in - 9) * inc), P.a_inf) : make_float2(1.f, 0.f);
 #pragma unroll
-            for (int q = 0; q < 10; q++) {
-                hp[q] = mix ? cmul(ph, xv[q]) : xv[q];
-                ph = cmul(st, ph);
+                for (int q = 0; q < 10; q++) {
+                    hp[q] = mix ? cmul(ph, xv[q]) : xv[q];
+                    ph = cmul(st, ph);
+                }
+            } else {
+                // k_mix_cic_hb's history: the last twelve sample pairs, each sample with its exact phase
+                const long long P0 = P.n_in / P.cic_s0 - 12;
+                float4 xv[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) xv[q] = *reinterpret_cast<const float4 *>(in + (P0 + q) * (long long)P.cic_s0);
+                const float2 st = mix ? cis_cycles(inc) : make_float2(1.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const float2 ph = mix ? cscale(cis_cycles(phase0 + (double)((P0 + q) * (long long)P.cic_s0 + 1) * inc), P.a_inf) : make_float2(1.f, 0.f);
+                    hp[2 * q] = mix ? cmul(ph, make_float2(xv[q].x, xv[q].y)) : make_float2(xv[q].x, xv[q].y);
+                    hp[2 * q + 1] = mix ? cmul(cmul(st, ph), make_float2(xv[q].z, xv[q].w)) : make_float2(xv[q].z, xv[q].w);
+                }
             }
         }
         return;
@@ -387,19 +404,22 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
         for (int p = 0; p < NP; p++) fetch_pair(it + 2, p, edgec);
         voff += 64u * S;
         v16f_t acc = zero16;
-        auto matrix_step = [&](int p, auto after) {
-            after(av[p]);
-            if constexpr ((DBG & 2) != 0 && !EDGE) acc[p] += av[p] * bco[p];  // (timing experiment: no matrix instructions in the plain blocks)
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bco[p], acc, 0, 0, 0);
+        // Eight places between the stages take the block's NP matrix instructions, ceil-spread (NP = 4: places 0 2 4 6; NP = 12: two,
+        // one, two, one ...); `after` ties the first one of a place to what the stage in front of it wrote
+        auto matrix_slot = [&](auto slotc, auto after) {
+            constexpr int i = decltype(slotc)::value, p_lo = (i * NP + 7) / 8, p_hi = ((i + 1) * NP + 7) / 8;
+            if constexpr (p_lo < p_hi) after(av[p_lo]);
+#pragma unroll
+            for (int p = p_lo; p < p_hi; p++) {
+                if constexpr ((DBG & 2) != 0 && !EDGE) acc[p] += av[p] * bco[p];  // (timing experiment: no matrix instructions in the plain blocks)
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bco[p], acc, 0, 0, 0);
+            }
         };
         auto behind_matrix = [&](float2 &x) { asm volatile("" : "+v"(x.x) : "v"(acc)); };
-        // (a front with more than four pairs -- a merged CIC3 in front of the hb11 -- issues the surplus first)
+        matrix_slot(std::integral_constant<int, 0>{}, [&](float &l) {
 #pragma unroll
-        for (int p = 0; p + 3 < NP; p++)
-            matrix_step(p, [&](float &l) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) asm volatile("" : "+v"(l) : "v"(y0[k].x));
-            });
+            for (int k = 0; k < 8; k++) asm volatile("" : "+v"(l) : "v"(y0[k].x));
+        });
         if constexpr (EDGE) {
             // first-stage outputs in front of the call's start come from the previous call's history: every warm-up block of a chunk
             // that starts there when that call left no running sums (it took another route), else only block o = 0 (its outputs 0..6;
@@ -438,22 +458,29 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
             for (int i = 0; i < N1; i++) asm volatile("" : "+v"(l) : "v"(a1[i].x));
         };
 #pragma unroll
-        for (int k = 0; k < 4; k++) behind_matrix(y0[k]);
+        for (int k = 0; k < 8; k++) behind_matrix(y0[k]);
+        hb1(0); hb1(1);
+        matrix_slot(std::integral_constant<int, 1>{}, after_a1);
+        if constexpr ((1 * NP + 7) / 8 < (2 * NP + 7) / 8) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) hb1(k);
-        if constexpr (NP >= 3) matrix_step(NP - 3, after_a1);
+            for (int k = 2; k < 8; k++) behind_matrix(y0[k]);
+        }
+        hb1(2); hb1(3);
+        matrix_slot(std::integral_constant<int, 2>{}, after_a1);
+        if constexpr ((2 * NP + 7) / 8 < (3 * NP + 7) / 8) {
 #pragma unroll
-        for (int k = 4; k < 8; k++) behind_matrix(y0[k]);
-#pragma unroll
-        for (int k = 4; k < 8; k++) hb1(k);
-        if constexpr (NP >= 2) matrix_step(NP - 2, after_a1);
+            for (int k = 4; k < 8; k++) behind_matrix(y0[k]);
+        }
+        hb1(4); hb1(5);
+        matrix_slot(std::integral_constant<int, 3>{}, after_a1);
+        if constexpr ((3 * NP + 7) / 8 < (4 * NP + 7) / 8) { behind_matrix(y0[6]); behind_matrix(y0[7]); }
+        hb1(6); hb1(7);
+        matrix_slot(std::integral_constant<int, 4>{}, after_a1);
         // halfband 2
 #pragma unroll
         for (int b = 0; b < 4; b++) behind_matrix(y1[b]);
         float2 y2[2];
-        if constexpr ((DBG & 4) != 0 && !EDGE) { y2[0] = y1[1]; y2[1] = y1[3]; }  // (timing experiment: no halfband 2)
-#pragma unroll
-        for (int b = 0; b < ((DBG & 4) != 0 && !EDGE ? 0 : 4); b++) {
+        auto hb2 = [&](int b) {
             if (b & 1) {
                 const int b2 = (b - 1) / 2;
 #pragma unroll
@@ -465,16 +492,27 @@ static __global__ __launch_bounds__(256, 2) void k_mix_dec_mfma(const float2 *__
             } else {
                 a2[(b + PC2 - 1) / 2] = a2[(b + PC2 - 1) / 2] + y1[b] * bc(hb_tap<T2>(PC2));
             }
-        }
-        matrix_step(NP - 1, [&](float &l) {
+        };
+        auto after_a2 = [&](float &l) {
 #pragma unroll
             for (int i = 0; i < N2; i++) asm volatile("" : "+v"(l) : "v"(a2[i].x));
-        });
+        };
+        if constexpr ((DBG & 4) != 0 && !EDGE) {  // (timing experiment: no halfband 2)
+            y2[0] = y1[1]; y2[1] = y1[3];
+        } else {
+            hb2(0); hb2(1);
+        }
+        matrix_slot(std::integral_constant<int, 5>{}, after_a2);
+        if constexpr ((5 * NP + 7) / 8 < (6 * NP + 7) / 8) { behind_matrix(y1[2]); behind_matrix(y1[3]); }
+        if constexpr ((DBG & 4) == 0 || EDGE) { hb2(2); hb2(3); }
+        matrix_slot(std::integral_constant<int, 6>{}, after_a2);
         behind_matrix(y2[0]);
         behind_matrix(y2[1]);
-        D = acc;
-        // halfband 3
+        // halfband 3: the centre tap's input, then the last place, then the even taps' input
         a3[(PC3 - 1) / 2] = a3[(PC3 - 1) / 2] + y2[0] * bc(hb_tap<T3>(PC3));
+        matrix_slot(std::integral_constant<int, 7>{}, [&](float &l) { asm volatile("" : "+v"(l) : "v"(a3[(PC3 - 1) / 2].x)); });
+        if constexpr ((7 * NP + 7) / 8 < (8 * NP + 7) / 8) behind_matrix(y2[1]);
+        D = acc;
 #pragma unroll
         for (int t = 0; t < H3; t++) {
             const float2 v = y2[1] * bc(hb_tap<T3>(T3 - 1 - 2 * t));

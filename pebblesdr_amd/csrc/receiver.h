@@ -81,6 +81,8 @@ struct OscBank {
 };
 
 // ---- Mixer + Decimator ----
+bool bank_variant(int np, int t1, int t2, int t3, int *hy, int *nstate, int *minw);  // a k_mix_dec_mfma instance exists for this front and triple
+
 struct DecimCore {
     design::Chain chain;
     uint32_t C = 0;
@@ -107,6 +109,8 @@ struct DecimCore {
     // the same chain with its first stage on the matrix pipe, one wave per (32 channels, two chunks): k_mix_dec_mfma (kernels_bank_dec.h),
     // the default route of such a bank; PEBBLEGPU_BANK_DEC=0 keeps the four-wave pipeline above
     bool bank_mfma = false;
+    int bank_nstate = 0, bank_minw = 2;          // running sums per channel of the chain's instance; waves per SIMD it admits
+    int run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, const OscBank &osc, bool had_state);
     int bank_waves = 0;                          // target waves per SIMD of a launch (PEBBLEGPU_BANK_WAVES, default 1)
     int xh_depth = 16;                           // samples of raw-input tail kept in d_xhist
     float2 *d_bank_state[2] = {nullptr, nullptr};  // [C][38] the halfbands' running sums where the last k_mix_dec_mfma call ended (ping-pong)
@@ -150,7 +154,7 @@ struct DecimCore {
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
             hipEvent_t after_first = nullptr, const RawSrc *raw = nullptr);
     // the first kernels this call would run read raw device-format samples themselves (k_mix_hb11_lean + its edge launch)
-    bool raw_ready(const OscBank &osc) const { return bank_front && C == 1 && want_lds_free && !osc.any_transient() && !(fused_all); }
+    bool raw_ready(const OscBank &osc) const { return bank_front && C == 1 && want_lds_free && !osc.any_transient() && !(fused_all || bank_mfma); }
     void tail_jobs(std::vector<TailJob> &jobs) const;  // after run(): what must be refreshed before the next call
     const HistBuf &out() const { return casc.nst > 0 ? fin : buf0; }
     long long out_len() const { return len_out; }

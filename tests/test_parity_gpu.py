@@ -1246,13 +1246,61 @@ def test_full_size_configs3_512_channel_shard(gpu_lib, oracle_mod):
         assert rel_rms(g[c], want) <= TOL
 
 
+def test_configs3_shard_over_three_calls(gpu_lib, oracle_mod):
+    """BASELINE configs[3], one GPU's shard (100 Msps, 512 AM / USB channels, chain cic3 x 16, hb11 x 16, hb15, hb23, hb47) over three calls
+    of one super-frame: the first inside the oscillators' transient (k_mix_cic_hb + k_cascade), the second and third in one kernel
+    (k_mix_dec_mfma with the CIC3 and the hb11 as one twelve-pair first stage), the second from the histories the first left, the third
+    from the second's running sums.  Oracle (mixer + decimator + band-pass [+ AM]) on four channels, every frame."""
+    import pebblesdr_amd as P
+    fs, C, K = 100_000_000, 512, 3
+    rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
+    sf = rx.superframe
+    rate = int(rx.info.demod_rate_int)
+    fcs = [-44.8e6 + 175e3 * c for c in range(C)]
+    lit = (0, 130, 333, 511)
+    t = np.arange(K * sf) / fs
+    x = lcg_noise(K * sf, 4, 1e-3)
+    for c in lit:
+        if c % 2 == 0:
+            x = x + 0.05 * (1 + 0.5 * np.cos(2 * np.pi * 800 * t)) * np.exp(2j * np.pi * fcs[c] * t)
+        else:
+            x = x + 0.05 * np.exp(2j * np.pi * (fcs[c] + 1200.0) * t)
+    del t
+    for c in range(C):
+        rx.set_mixer(c, fcs[c])
+        if c % 2 == 0:
+            rx.set_mode(c, P.DM_AM); rx.set_bandpass(c, -5000, 5000)
+        else:
+            rx.set_mode(c, P.DM_USB); rx.set_bandpass(c, 300, 3000)
+    g, names = [], []
+    for k in range(K):
+        g.append(rx.process(x[k * sf:(k + 1) * sf])[0])
+        names.append(rx.kernel_name(2))
+    g = np.concatenate(g, axis=1)
+    assert names[0] == "k_mix_cic_hb" and names[1] == "k_mix_dec_mfma" and names[2] == "k_mix_dec_mfma", names
+    for c in lit:
+        mix = oracle_mod.Mixer(fs); mix.set_frequency(fcs[c])
+        dec = oracle_mod.Decimator(fs, 30000)
+        z = np.concatenate([dec.process(mix.process(x[k * sf:(k + 1) * sf])) for k in range(K)]) * 10 ** (2 * 11 / 20.0)
+        ff = oracle_mod.FastFIR()
+        if c % 2 == 0:
+            ff.setup(-5000, 5000, 0, rate)
+            am = oracle_mod.DemodAM(rate, 10000)
+            want = np.concatenate([am.process(ff.process(z[k:k + 2048])) for k in range(0, len(z), 2048)])
+        else:
+            ff.setup(300, 3000, 0, rate)
+            want = np.concatenate([ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048)])
+        for k in range(K):
+            assert rel_rms(g[c][k * 2048:(k + 1) * 2048], want[k * 2048:(k + 1) * 2048]) <= TOL, (c, k)
+
+
 @pytest.mark.parametrize("fs,C", [(1024000, 3), (2400000, 17), (3200000, 1), (5000000, 17), (8000000, 3), (10000000, 1), (10000000, 17),
                                   (16000000, 3), (25000000, 17), (40000000, 1), (40000000, 3)])
 def test_chain_sweep_over_rates_and_bank_sizes(gpu_lib, oracle_mod, fs, C):
     """Every first-stage form the ladder of decimator.cpp:74-146 produces between 1 and 40 Msps -- hb11 merged 2/4/8/16 times
     (LDS-tiled for few channels, in registers for a bank, the stride-16 one peeled off the cascade) and CIC3 merged 1/2/3 times
     in front of hb11 x 16 (the fused register front end) -- for one channel, a few and a ragged bank off one shared stream: USB
-    audio of the first and last channel against Mixer -> Decimator -> gain restore -> FastFIR restated by the oracle, two
+    audio of the first and last channel against Mixer -> Decimator -> gain restore -> FastFIR restated by the oracle, three
     calls.  The oracle is fed whole super-frames so that none of its stages sees fewer samples than taps."""
     import pebblesdr_amd as P
     rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=1)
@@ -1263,17 +1311,26 @@ def test_chain_sweep_over_rates_and_bank_sizes(gpu_lib, oracle_mod, fs, C):
     for c in range(C):
         rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
     sf = rx.superframe
-    x = tones(fs, 2 * sf, [(0.05, fc + 1000.0 + 50.0 * i) for i, fc in enumerate(fcs)]) + lcg_noise(2 * sf, 5, 1e-3)
-    g = np.concatenate([rx.process(x[:sf])[0], rx.process(x[sf:])[0]], axis=1)
+    K = 3  # calls: the first inside the oscillators' transient, the second from the histories it left, the third from the running sums of the second
+    x = tones(fs, K * sf, [(0.05, fc + 1000.0 + 50.0 * i) for i, fc in enumerate(fcs)]) + lcg_noise(K * sf, 5, 1e-3)
+    g, names = [], []
+    for k in range(K):
+        g.append(rx.process(x[k * sf:(k + 1) * sf])[0])
+        names.append(rx.kernel_name(2))
+    g = np.concatenate(g, axis=1)
+    if C >= 16:
+        # every bank of >= 16 channels whose chain is [cic3 x S0,] hb11 x S + three halfbands runs its whole decimator in one kernel
+        # once the oscillators have settled
+        assert names[1] == "k_mix_dec_mfma" and names[2] == "k_mix_dec_mfma", (names, chain)
     for c in sorted({0, C - 1}):
         mix = oracle_mod.Mixer(fs); mix.set_frequency(fcs[c])
         dec = oracle_mod.Decimator(fs, 30000)
         assert dec.chain() == chain
-        z = np.concatenate([dec.process(mix.process(x[:sf])), dec.process(mix.process(x[sf:]))]) * 10 ** (2 * stages / 20.0)
+        z = np.concatenate([dec.process(mix.process(x[k * sf:(k + 1) * sf])) for k in range(K)]) * 10 ** (2 * stages / 20.0)
         ff = oracle_mod.FastFIR(); ff.setup(300, 3000, 0, rate)
         r = np.concatenate([ff.process(z[k:k + 2048]) for k in range(0, len(z), 2048)])
         assert r.shape == g[c].shape
-        for k in range(2):
+        for k in range(K):
             assert rel_rms(g[c][k * 2048:(k + 1) * 2048], r[k * 2048:(k + 1) * 2048]) <= TOL, "channel %d call %d chain %s" % (c, k, chain)
 
 
