@@ -274,24 +274,50 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     auto straddles = [&](int it) {
         return pair == 0 && ((it >= WARM && it < WARM + o_safe) || (it >= WARM - L && it < WARM - L + o_safe));
     };
-    // the two raw samples of pair p for block `it` of both chunks (block index relative to the chunks' first block); `voff` is that block's
-    auto fetch_pair = [&](int it, int p, auto edgec) {
+    // the raw samples of block `it` of both chunks (block index relative to the chunks' first block); `voff` is that block's
+    typedef unsigned v3u_t __attribute__((ext_vector_type(3)));
+    auto fetch_all = [&](int it, auto edgec) {
         if constexpr (!decltype(edgec)::value && (DBG & 1) != 0) return;  // (timing experiment: no sample fetches in the plain blocks)
         bool slow = false;
         if constexpr (decltype(edgec)::value) slow = straddles(it);
         if (!slow) {
             const unsigned vc = voff < vmax ? voff : vmax;
-            ld[2 * p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.oa[p] - P.min_off), 0));
-            ld[2 * p + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.ob[p] - P.min_off), 0));
+            if constexpr (NP == 12) {
+                // A merged CIC3 in front: its window is twelve sample pairs x[S0 t], x[S0 t + 1] (t = 0 .. 11 from the window's first sample),
+                // one 128-byte line each at S0 = 16 -- and each line serves two of the twelve symmetric pairs: (od_{11-i}, ev_i) and
+                // (ev_{11-i}, od_i).  One 12-byte load per line and lane ([ev.c, the other component, od.c]) touches every line ONCE; with
+                // a 4-byte load per operand each line was touched four times by a wave whose working set (192 lines per block, four
+                // waves) does not fit the CU's vector cache: 4.5 GB through L2 per configs[3] call, 0.158 ms against 0.094 (two 4-byte
+                // loads per line, back to back: 0.161 -- the second does not meet the first one's miss)
+                v3u_t ln[12];
+#pragma unroll
+                for (int t = 0; t < 12; t++) ln[t] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, vc, 8 * P.cic_s0 * t, 0);
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    ld[4 * i] = __uint_as_float(ln[11 - i].z);      // pair 2 i: (od of line 11 - i, ev of line i)
+                    ld[4 * i + 1] = __uint_as_float(ln[i].x);
+                    ld[4 * i + 2] = __uint_as_float(ln[11 - i].x);  // pair 2 i + 1: (ev of line 11 - i, od of line i)
+                    ld[4 * i + 3] = __uint_as_float(ln[i].z);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+                    ld[2 * p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.oa[p] - P.min_off), 0));
+                    ld[2 * p + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.ob[p] - P.min_off), 0));
+                }
+            }
         } else {
             const long long sj = (long long)S * (8 * (oA_start + it) - 7 + kA);
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                long long i = sj + (q == 0 ? P.oa[p] : P.ob[p]);
-                i = i < P.n_in ? i : P.n_in - 1;
-                long long ih = (long long)P.xh + i;  // in front of the call: the previous call's tail (never used when older than that)
-                ih = ih > 0 ? ih : 0;
-                ld[2 * p + q] = i >= 0 ? inf[2 * i + compL] : xhf[2 * ih + compL];
+            for (int p = 0; p < NP; p++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    long long i = sj + (q == 0 ? P.oa[p] : P.ob[p]);
+                    i = i < P.n_in ? i : P.n_in - 1;
+                    long long ih = (long long)P.xh + i;  // in front of the call: the previous call's tail (never used when older than that)
+                    ih = ih > 0 ? ih : 0;
+                    ld[2 * p + q] = i >= 0 ? inf[2 * i + compL] : xhf[2 * ih + compL];
+                }
             }
         }
     };
@@ -309,14 +335,12 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     // prologue: block 0 through the matrix pipe, block 1's samples on their way
     {
         v16f_t acc = zero16;
-#pragma unroll
-        for (int p = 0; p < NP; p++) fetch_pair(0, p, std::true_type{});
+        fetch_all(0, std::true_type{});
 #pragma unroll
         for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]), bco[p], acc, 0, 0, 0);
         D = acc;
         voff += 64u * S;
-#pragma unroll
-        for (int p = 0; p < NP; p++) fetch_pair(1, p, std::true_type{});
+        fetch_all(1, std::true_type{});
         voff += 64u * S;
     }
 
@@ -400,8 +424,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         float av[NP];
 #pragma unroll
         for (int p = 0; p < NP; p++) av[p] = __builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]);
-#pragma unroll
-        for (int p = 0; p < NP; p++) fetch_pair(it + 2, p, edgec);
+        fetch_all(it + 2, edgec);
         voff += 64u * S;
         v16f_t acc = zero16;
         // Eight places between the stages take the block's NP matrix instructions, ceil-spread (NP = 4: places 0 2 4 6; NP = 12: two,
@@ -415,7 +438,12 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
                 else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bco[p], acc, 0, 0, 0);
             }
         };
-        auto behind_matrix = [&](float2 &x) { asm volatile("" : "+v"(x.x) : "v"(acc)); };
+        // (an instance that is given the whole register file keeps its accumulator in the AGPRs: a pin that asked for it in VGPRs cost
+        // sixteen v_accvgpr_read each)
+        auto behind_matrix = [&](float2 &x) {
+            if constexpr (MINW == 1) asm volatile("" : "+v"(x.x) : "a"(acc));
+            else asm volatile("" : "+v"(x.x) : "v"(acc));
+        };
         matrix_slot(std::integral_constant<int, 0>{}, [&](float &l) {
 #pragma unroll
             for (int k = 0; k < 8; k++) asm volatile("" : "+v"(l) : "v"(y0[k].x));
