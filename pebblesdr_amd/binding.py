@@ -453,7 +453,7 @@ class StreamBank:
 
     def spectrum_kernels(self):
         """label of the kernels behind last_ms(2)"""
-        return "k_big_cols + k_big_rows" if self.frame == 65536 else "k_spectrum"
+        return ("k_big_cols + k_big_rows" if os.environ.get("PEBBLEGPU_BIG_SPLIT32") == "1" else "k_big256_cols + k_big256_rows") if self.frame == 65536 else "k_spectrum"
 
     def filtered(self):
         n, pitch = C.c_uint64(), C.c_uint64()

@@ -1814,9 +1814,16 @@ int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, lon
         sp.out_pitch = F * (long long)bins;
         for (long long s0 = 0; s0 < (long long)S; s0 += bs) {
             const unsigned nb = (unsigned)((long long)S - s0 < bs ? (long long)S - s0 : bs);
-            launch(k_big_cols, dim3((unsigned)(F * 8), nb), dim3(256), s, d_in + s0 * in_pitch, (long long)in_pitch, d_Y, (const float *)d_window, (long long)F);
-            launch(k_big_rows, dim3((unsigned)(cdiv(F, G) * 8), nb), dim3(256), s, (const float2 *)d_Y, d_out + s0 * sp.out_pitch, (const float2 *)d_tw_nf,
-                   (const float *)d_prev[parity] + s0 * kBigN, d_prev[parity ^ 1] + s0 * kBigN, sp);
+            static const bool split32 = [] { const char *e = getenv("PEBBLEGPU_BIG_SPLIT32"); return e && e[0] == '1'; }();  // A/B: the 32 x 2048 split
+            if (split32) {
+                launch(k_big_cols, dim3((unsigned)(F * 8), nb), dim3(256), s, d_in + s0 * in_pitch, (long long)in_pitch, d_Y, (const float *)d_window, (long long)F);
+                launch(k_big_rows, dim3((unsigned)(cdiv(F, G) * 8), nb), dim3(256), s, (const float2 *)d_Y, d_out + s0 * sp.out_pitch, (const float2 *)d_tw_nf,
+                       (const float *)d_prev[parity] + s0 * kBigN, d_prev[parity ^ 1] + s0 * kBigN, sp);
+            } else {
+                launch(k_big256_cols, dim3((unsigned)(F * 8), nb), dim3(256), s, d_in + s0 * in_pitch, (long long)in_pitch, d_Y, (const float *)d_window, (long long)F);
+                launch(k_big256_rows, dim3((unsigned)(cdiv(F, G) * 8), nb), dim3(256), s, (const float2 *)d_Y, d_out + s0 * sp.out_pitch,
+                       (const float *)d_prev[parity] + s0 * kBigN, d_prev[parity ^ 1] + s0 * kBigN, sp);
+            }
         }
         parity ^= 1;
         PG_HIP(hipGetLastError());

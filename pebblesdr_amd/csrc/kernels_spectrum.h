@@ -1037,6 +1037,161 @@ static __global__ __launch_bounds__(256, 2) void k_big_rows(const float2 *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same spectrum as 256 x 256 (n = 256 n1 + n2, k = k1 + 256 k2): every global access of both passes is a whole 128- or
+// 256-byte segment.  In the 32 x 2048 split above pass B's bins k1 + 32 k2 of one row lie 128 bytes apart: four rows per
+// workgroup made 16-byte pieces, eight workgroups wrote into every line, and the pass ran 229 us for 402 MB (pass A: 95 us for
+// 536 MB).
+//   X[k1 + 256 k2] = sum_{n2} W_256^{n2 k2} * [ W_N^{n2 k1} * sum_{n1} w[n] x[n] W_256^{n1 k1} ]
+//   pass A (k_big256_cols): a workgroup takes 32 adjacent columns n2 (256-byte row segments); work-item (column c, j) runs the
+//           256-point transform of its column as 16 x 16: two DFT16 over a (n1 = 16 a + b, b = j, j + 8), twiddle W_256^{b cc},
+//           exchange through LDS [cc][b][column], two DFT16 over b (cc = j, j + 8), the four-step twiddle W_N^{n2 k1} as a power
+//           series from three exact phasors, Y[k1][n2] stored as 256-byte segments;
+//   pass B (k_big256_rows): a workgroup takes 32 adjacent rows k1, sixteen at a time, sixteen work-items per row (128-byte
+//           loads): DFT16 over a (n2 = 16 a + b), twiddle (per work-item constants), exchange inside the row's sixteen lanes
+//           (wave-private LDS, padded), DFT16 over b, amplitude / previous-frame average (registers, along a chain of frames) /
+//           dB, parked as floats [k2][k1] in LDS; then every bin line k1 .. k1 + 31 of one k2 leaves as one 128-byte segment
+//           (unfolded: k2 ^ 128), nontemporal.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBig256 = 256;
+
+// grid (frames * 8, S), block 256.  Y layout: [stream][frame][k1][n2]
+static __global__ __launch_bounds__(256, 2) void k_big256_cols(const float2 *__restrict__ in, long long in_pitch, float2 *__restrict__ Y,
+                                                               const float *__restrict__ window, long long n_frames)
+{
+    __shared__ float2 T[256 * 32];   // [cc * 16 + b][column]
+    __shared__ float2 tw[256];       // W_256^m
+    const int t = threadIdx.x, c = t & 31, j = t >> 5;
+    const int s = blockIdx.y;
+    const long long f = blockIdx.x >> 3;
+    const int n2 = ((blockIdx.x & 7) << 5) + c;
+    tw[t] = cis_cycles(-(double)t / 256.0);
+    const float2 *x = in + (long long)s * in_pitch + f * kBigN + n2;
+    const float *w = window + n2;
+    float2 u[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            const int n1 = 16 * a + j + 8 * h;
+            u[h][a] = cscale(x[(long long)kBig256 * n1], w[kBig256 * n1]);
+        }
+    __syncthreads();  // (the twiddle table)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int b = j + 8 * h;
+        dft16(u[h]);
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) {
+            const float2 v = u[h][perm16(cc)];
+            T[(cc * 16 + b) * 32 + c] = cc == 0 ? v : cmul(tw[(b * cc) & 255], v);
+        }
+    }
+    __syncthreads();
+    // W_N^{n2 k1}, k1 = cc + 16 d: exact phasors for cc = j, j + 8 and for 16, then a power series over d
+    const float2 w16 = cis_cycles(-(double)(16 * n2) / (double)kBigN);
+    float2 *y = Y + ((long long)s * n_frames + f) * kBigN + n2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int cc = j + 8 * h;
+        float2 v[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) v[b] = T[(cc * 16 + b) * 32 + c];
+        dft16(v);
+        float2 ph = cis_cycles(-(double)(cc * n2) / (double)kBigN);
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            y[(long long)kBig256 * (cc + 16 * d)] = cmul(ph, v[perm16(d)]);
+            ph = cmul(w16, ph);
+        }
+    }
+}
+
+// grid (ceil(n_frames / G) * 8, S), block 256: rows k1 = 32 (blockIdx.x & 7) + 16 pass + (t >> 4), sixteen work-items per row
+static __global__ __launch_bounds__(256, 2) void k_big256_rows(const float2 *__restrict__ Y, float *__restrict__ out, const float *__restrict__ prev_in,
+                                                               float *__restrict__ prev_out, SpectrumParams sp)
+{
+    __shared__ float2 T[16 * 16 * 17];  // [row][cc][b], a pad slot per run of sixteen
+    __shared__ float db[256 * 33];      // [k2][k1 - first], a pad slot per line
+    const int t = threadIdx.x, bb = t & 15, rl = t >> 4;
+    const int s = blockIdx.y, rt = blockIdx.x & 7;
+    const int G = sp.frames_per_group;
+    const long long f0 = (long long)(blockIdx.x >> 3) * G;
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
+    // W_256^{bb cc}, cc = 1 .. 15
+    float2 twr[16];
+    twr[0] = make_float2(1.f, 0.f);
+    twr[1] = cis_cycles(-(double)bb / 256.0);
+#pragma unroll
+    for (int cc = 2; cc < 16; cc++) twr[cc] = cis_cycles(-(double)(bb * cc) / 256.0);
+    float pa[2][16];
+    float2 *Tr = T + rl * 16 * 17;
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        const bool live = f < sp.n_frames;
+        if (live && f < 0) {
+            const float *pp = prev_in + (long long)s * kBigN + (long long)rt * 8192 + t;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int d = 0; d < 16; d++) pa[h][d] = pp[(h * 16 + d) * 256];
+        } else if (live) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k1 = 32 * rt + 16 * h + rl;
+                const float2 *row = Y + (((long long)s * sp.n_frames + f) * kBig256 + k1) * kBig256 + bb;
+                float2 u[16];
+#pragma unroll
+                for (int a = 0; a < 16; a++) u[a] = row[16 * a];
+                dft16(u);
+                wave_sync();  // (the row's sixteen lanes have read what the previous pass parked)
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) Tr[cc * 17 + bb] = cc == 0 ? u[perm16(0)] : cmul(twr[cc], u[perm16(cc)]);
+                wave_sync();
+                float2 v[16];
+#pragma unroll
+                for (int b = 0; b < 16; b++) v[b] = Tr[bb * 17 + b];  // (this work-item's cc is its lane index in the row)
+                dft16(v);
+                float mag[16];
+#pragma unroll
+                for (int d = 0; d < 16; d++) {
+                    const float2 z = v[perm16(d)];
+                    mag[d] = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
+                }
+#pragma unroll
+                for (int d = 0; d < 16; d++) {
+                    const float a = mag[d] + pa[h][d];
+                    pa[h][d] = mag[d];
+                    mag[d] = __builtin_amdgcn_logf(a);
+                }
+                if (it >= 0) {
+#pragma unroll
+                    for (int d = 0; d < 16; d++)  // k2 = bb + 16 d
+                        db[(bb + 16 * d) * 33 + 16 * h + rl] = fminf(fmaxf(fmaf(6.02059991327962f, mag[d], db_off), -120.f), 0.f);
+                }
+            }
+            if (f == sp.n_frames - 1) {
+                float *pp = prev_out + (long long)s * kBigN + (long long)rt * 8192 + t;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int d = 0; d < 16; d++) pp[(h * 16 + d) * 256] = pa[h][d];
+            }
+        }
+        __syncthreads();
+        if (it >= 0 && live) {
+            // lines of 32 bins: k = 32 rt + lane + 256 k2, unfolded to k2 ^ 128 (fft.cpp:207-213)
+            float *yf = out + (long long)s * sp.out_pitch + f * (long long)kBigN + 32 * rt + (t & 31);
+#pragma unroll 8
+            for (int i = 0; i < 32; i++) {
+                const int k2 = 8 * i + (t >> 5);
+                store_stream(yf + 256 * (k2 ^ 128), db[k2 * 33 + (t & 31)]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // (Pass B was also built on the two-wave transform of fft_t128.h -- 512-item workgroups, four rows x two waves, four waves per
 // SIMD -- and measured slower, 0.39 ms against 0.32 for the bench shard: its rows wait on workgroup-wide barriers and on their
 // own loads, where here every wave runs alone.)

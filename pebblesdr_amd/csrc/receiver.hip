@@ -553,7 +553,7 @@ int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, ui
 const char *Receiver::kernel_name(int which) const
 {
     switch (which) {
-    case 1: return !bins ? "" : spec_.big ? "k_big_cols + k_big_rows" : spec_.per_q ? "k_spectrum_q128" : bins == 8192 ? (spec_.use_w64 ? "k_spectrum_w64" : spec_.last_fullc ? "k_spectrum_t128 (twiddles held)" : "k_spectrum_t128") : bins == 4096 ? "k_spectrum<2>" : "k_spectrum_1to1";
+    case 1: return !bins ? "" : spec_.big ? "k_big256_cols + k_big256_rows" : spec_.per_q ? "k_spectrum_q128" : bins == 8192 ? (spec_.use_w64 ? "k_spectrum_w64" : spec_.last_fullc ? "k_spectrum_t128 (twiddles held)" : "k_spectrum_t128") : bins == 4096 ? "k_spectrum<2>" : "k_spectrum_1to1";
     case 2: return dec_.front_name;
     case 3: return dec_.rest_name;
     case 4: return wfm ? "" : ff_n == 2048 ? "k_fastfir_t128" : "k_fastfir";
