@@ -242,8 +242,8 @@ int pebblegpu_process_iq(pebblegpu_receiver *rx, const double *iq, uint16_t n, d
  * Stream bank: S independent full-rate IQ streams, each through the overlap-save band-pass
  * (CFastFIR::ProcessData, pebblelib/fastfir.cpp:281-334, one filter per stream) and the display
  * transform (FFT::fftSpectrum, pebblelib/fft.cpp:317-374) at the stream rate -- the two transforms of
- * Receiver::processIQData with no tuner/decimator in front (BASELINE.json configs[4]: 64 streams,
- * 65536-point spectrum, 2048/1025 band-pass).  Device buffers, one process per GPU, streams shard
+ * Receiver::processIQData with no tuner/decimator in front (BASELINE.json configs[4]: 1024 streams over 8 GPUs,
+ * 128 per GPU, 65536-point spectrum, 2048/1025 band-pass).  Device buffers, one process per GPU, streams shard
  * across ranks with no exchange.  frame/spectrum_bins: 2048-sample frames with 2048/4096/8192 bins
  * (the reference's setup), or 65536/65536, which is past the reference's own m_maxFFTSize clamp
  * (fft.h:21) and uses the same formulas with the clamp lifted.

@@ -773,12 +773,14 @@ def test_config5_streambank_small(gpu_lib, oracle_mod):
                     assert db_err(sp[c, f], r) <= TOL_DB
 
 
-def test_config5_streambank_full_size(gpu_lib, oracle_mod):
-    """BASELINE configs[4] at size: 64 streams x 8 frames (33.5 M samples per call, frames chained two per wave group).
-    Oracle on three whole streams; for all 64, call-splitting invariance (one 8-frame call == eight 1-frame calls:
-    bit-exact, both carry states are exact) and a bin-centred tone reading its level at its bin in every frame."""
+@pytest.mark.parametrize("S,F", [(128, 4), (64, 8)])
+def test_config5_streambank_full_size(gpu_lib, oracle_mod, S, F):
+    """BASELINE configs[4] at size: 128 streams x 4 frames -- bench.py's own shard geometry -- and 64 x 8 (33.5 M samples per call
+    either way; the spectrum's frame chains run 4 and 8 long).  Oracle on three whole streams; for all streams, call-splitting
+    invariance (one F-frame call == F 1-frame calls: bit-exact, both carry states are exact) and a bin-centred tone reading its
+    level at its bin in every frame."""
     import pebblesdr_amd as P
-    fs, S, N, F = 2.0e6, 64, 65536, 8
+    fs, N = 2.0e6, 65536
     t = np.arange(F * N) / fs
     x = np.empty((S, F * N), dtype=np.complex64)
     kbin = [1000 + 37 * c for c in range(S)]
@@ -797,7 +799,7 @@ def test_config5_streambank_full_size(gpu_lib, oracle_mod):
     for c in range(S):
         assert np.all(np.argmax(SA[c, 1:], axis=1) == N // 2 + kbin[c])
         assert np.abs(SA[c, 1:].max(axis=1) + 10.0).max() < 2e-3
-    for c in (0, 17, 63):
+    for c in (0, 17, S - 1):
         f_ref, s_ref = _streambank_refs(oracle_mod, fs, [bands[c]], N)[0]
         assert rel_rms(YA[c], f_ref.process(x[c])) <= TOL
         for f in range(F):
