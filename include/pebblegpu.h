@@ -145,8 +145,9 @@ int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_h
 /* Receiver::demodModeChanged -> Demod::setDemodMode (receiver.cpp:640-655).  Narrow banks accept AM, SAM, FMN and
  * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM (mono) and FMS.
  * FMS returns what Demod_WFM::processDataStereo (demod_wfm.cpp:255-365) delivers once its pilot PLL has dropped out, which it
- * does within the first blocks on any input (the phase detector of processPilotPll, :390-430 / :792-821, is discontinuous at
- * the loop's operating point; pinned on the oracle's line-by-line restatement, tests/test_oracle_pins.py): the discriminator
+ * does within the first blocks on every input it has been tried on (the phase detector of processPilotPll, :390-430 / :792-821,
+ * is discontinuous at the loop's operating point; pinned on the oracle's line-by-line restatement with clean, noisy and absent
+ * pilots at the demodulator rates the receiver runs, tests/test_oracle_pins.py -- other inputs: parity unpinned): the discriminator
  * output WITHOUT processDataMono's 75 kHz pre-filter, low-passed, de-emphasised and notched, the same signal in both
  * channels.  Not reproduced: the blocks before the drop-out (at most the first three of a stream, where the reference
  * demultiplexes with an unsettled pilot phase) and the RDS bit decoder (GUI text). */
@@ -183,7 +184,12 @@ const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *
 const void *pebblegpu_receiver_zoom_spectrum(const pebblegpu_receiver *rx, uint64_t *frames_per_channel, uint32_t *bins);
 /* Time of the last process call's kernels in ms, from HIP events on the library's stream.  which: 0 whole
  * call; 1 spectrum kernel; 2 mixer+first-decimator kernel; 3 remaining decimator stages; 4 FastFIR;
- * 5 demod. */
+ * 5 demod.  A call whose chain runs beside its display transform records no end event of its own: which = 0
+ * of such a call runs to the start event of the NEXT call on the handle (recorded behind that call's control
+ * updates and, for raw input that is staged, its conversion pass), or to the pebblegpu_receiver_synchronize /
+ * timing query that closes it -- back to back the sum over calls is the wall time, a single call's figure
+ * includes whatever the host let pass before it queued the next one.  PEBBLEGPU_EVENTS=full (read when the
+ * receiver is created) gives every call an end event of its own. */
 int pebblegpu_receiver_last_ms(const pebblegpu_receiver *rx, int which, float *ms);
 /* name(s) of the kernel(s) behind group `which` (1..5) as the last process call ran them ("" when the group is empty): the
  * bench labels its per-kernel roofline lines with these */
@@ -223,7 +229,9 @@ const void *pebblegpu_receiver_signal_strength(const pebblegpu_receiver *rx, uin
  *   - a narrow bank, or calls of several super-frames: one threshold per channel, the decision per (channel, super-frame) made on
  *     the device from the same call's spectra (no read-back, no synchronisation); a closed (channel, super-frame) reads as
  *     silence in the bank's audio rows (the count is common to all channels), and with audio_rate set the resampler sees that
- *     silence (a single Receiver's resampler would have slept).  WFM banks: PEBBLEGPU_E_UNSUPPORTED. */
+ *     silence (a single Receiver's resampler would have slept).  A WFM receiver with more than one channel, or one created
+ *     for several super-frames per call: a threshold above -120 is PEBBLEGPU_E_UNSUPPORTED (-120 and below, "never closes", is
+ *     accepted and does nothing). */
 int pebblegpu_set_squelch(pebblegpu_receiver *rx, uint32_t channel, double squelch_db);
 /* waits until every process call made on this handle has finished: its outputs are then valid and its input may be reused */
 int pebblegpu_receiver_synchronize(pebblegpu_receiver *rx);

@@ -278,10 +278,10 @@ void OscBank::advance(uint64_t n)
     }
 }
 
-int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale)
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, const float *final_scale)
 {
     double scale = gain;
-    if (final_scale != 0.f) scale = (double)final_scale;  // the caller has already folded the format's constant in
+    if (final_scale != nullptr) scale = (double)*final_scale;  // the caller has already folded the format's constant in (a gain of 0 included)
     else if (fmt == 0 || fmt == 1) scale *= 1 / 128.0;   // deviceinterfacebase.cpp:651,689
     else if (fmt == 2) scale *= 1 / 32768.0;             // :729
     else if (fmt == 4) scale *= 1 / 32767.0;             // wavfile.cpp:299-300

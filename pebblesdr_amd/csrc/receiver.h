@@ -39,7 +39,7 @@ int make_twiddles_t128(float2 **d_tw);
 int make_twiddles_t128q(float2 **d_tw);  // four tables, the pruned transform's per-work-item factor folded in (k_spectrum_t128)
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa = nullptr);
 int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa);  // 0, or a failure code (too many / too deep)
-int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, float final_scale = 0.f);
+int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, const float *final_scale = nullptr);
 int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
                   int stride, uint32_t channels);
 int run_gate_zero(hipStream_t s, float2 *audio, long long pitch, long long spf, const unsigned char *d_gate, int stride, uint32_t channels, int k);

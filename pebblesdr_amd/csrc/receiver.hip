@@ -170,7 +170,10 @@ int Receiver::set_squelch(uint32_t ch, double squelch_db)
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u of %u", ch, C);
     if (C != 1 || max_sf != 1) {
         // a bank, or calls of several super-frames: per-channel thresholds, the decision per (channel, super-frame) on the device
-        if (wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the per-channel gate of a bank is built for the narrow branch (a WFM receiver gates as one channel, one super-frame per call)");
+        if (wfm) {
+            if (squelch_db <= -120.0) return 0;  // "never closes": nothing to set up
+            return fail(PEBBLEGPU_E_UNSUPPORTED, "the per-channel gate of a bank is built for the narrow branch (a WFM receiver gates as one channel, one super-frame per call)");
+        }
         if (squelch_db > -120.0) {
             if (int rc = enable_smeter(true)) return rc;
         }
@@ -323,6 +326,12 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
                     (unsigned long long)superframe);
     if (with_spectrum && (!bins || n % nf != 0 || n > (uint64_t)max_sf * superframe))
         return fail(PEBBLEGPU_E_SIZE, "spectrum needs whole frames of %u samples within capacity", nf);
+    // caller mistakes around the squelch gate are refused HERE, before anything is queued: they leave the handle usable (a failure
+    // behind this point has kernels in flight and histories half advanced, and closes the handle)
+    if (with_chain && squelch_db_ > -120.0 && !with_spectrum && !last_spec_frames)
+        return fail(PEBBLEGPU_E_INVALID, "the squelch gate needs a spectrum: none has been computed yet");
+    if (with_chain && !wfm && bank_gate_ && !with_spectrum && !(squelch_db_ > -120.0) && !(C == 1 && ctl_[0].mode == PEBBLEGPU_DM_NONE))
+        return fail(PEBBLEGPU_E_INVALID, "the squelch gate of a bank reads the spectra of the same call: create the bank with spectrum_bins");
     // side by side: the chain goes to its own stream while the display transform keeps the arithmetic units busy (only when
     // the chain's first kernel needs no LDS -- the transform's workgroups leave none -- and nothing downstream reads the
     // spectrum or a conditioned copy of the input)
@@ -356,7 +365,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             if (plain) { if (int rc = join()) return rc; }  // the staging buffer is shared by successive calls
             if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
             // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
-            if (int rc = run_normalize_iq(raw->fmt, raw->order, 1.0, raw->base, (long long)(S * n), d_raw_stage_, stream_, false, raw->scale)) return rc;
+            if (int rc = run_normalize_iq(raw->fmt, raw->order, 1.0, raw->base, (long long)(S * n), d_raw_stage_, stream_, false, &raw->scale)) return rc;
             d_iq = d_raw_stage_;
             raw = nullptr;
         }

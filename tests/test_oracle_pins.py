@@ -391,21 +391,27 @@ def test_squelch_is_an_early_return_that_freezes_the_demodulator(oracle_mod):
     assert sum(len(a) for a in run(-10.0)) == 0  # a threshold above the carrier's average: every super-frame is gated
 
 
-def test_wfm_stereo_pilot_pll_of_the_reference_does_not_hold_lock(oracle_mod):
-    """Why FM-Stereo is not on the device path.  Restated line by line (processDataStereo,
+@pytest.mark.parametrize("fs", [256000.0, 312500.0, 390625.0])
+@pytest.mark.parametrize("pilot", ["clean", "noisy", "weak", "absent"])
+def test_wfm_stereo_pilot_pll_of_the_reference_does_not_hold_lock(oracle_mod, fs, pilot):
+    """Why FM-Stereo is not demultiplexed on the device path.  Restated line by line (processDataStereo,
     demod_wfm.cpp:255-297; processPilotPll :392-429; arctan2 :792-821), the pilot PLL steers its NCO onto 19 kHz but its
     phase detector -- Demod_WFM::arctan2 with 2*pi where the textbook approximation has pi/2 -- is discontinuous next to
-    the loop's operating point, so the loop ends in a limit cycle (|error| ~ 2.36 rad), the lock average climbs past
-    LOCK_MAG_THRESHOLD within the first blocks for every pilot phase, and from then on the block copies the mono signal to
-    both channels.  What the reference's dmFMS produces is therefore its mono discriminator output without the 75 kHz
-    pre-filter; there is no stereo separation to be bit-compatible with."""
-    fs = 256000.0
+    the loop's operating point, so the loop ends in a limit cycle, the lock average climbs past LOCK_MAG_THRESHOLD within the
+    first blocks for every pilot phase, and from then on the block copies the mono signal to both channels.  What the
+    reference's dmFMS produces is therefore its mono discriminator output without the 75 kHz pre-filter; there is no stereo
+    separation to be bit-compatible with.  Pinned at the three demodulator rates the WFM chains of the ladder end on (256, 312.5
+    and 390.625 kHz) with a 10 % pilot, the same under 2 % noise, a 3 % pilot and none; anything else: parity unpinned."""
+    from tests.signals import lcg_noise
     n, blocks = 2048, 24
     t = np.arange(n * blocks) / fs
     left, right = 0.9 * np.sin(2 * np.pi * 1000 * t), 0.9 * np.sin(2 * np.pi * 2500 * t)
+    amp = {"clean": 0.1, "noisy": 0.1, "weak": 0.03, "absent": 0.0}[pilot]
     for ph in (0.0, 1.0, 2.5, 3.67, 5.0):
-        mpx = 0.45 * (left + right) + 0.1 * np.sin(2 * np.pi * 19000 * t + ph) + 0.45 * (left - right) * np.sin(2 * (2 * np.pi * 19000 * t + ph))
+        mpx = 0.45 * (left + right) + amp * np.sin(2 * np.pi * 19000 * t + ph) + 0.45 * (left - right) * np.sin(2 * (2 * np.pi * 19000 * t + ph))
         x = 0.5 * np.exp(1j * 2 * np.pi * 75000 * np.cumsum(mpx) / fs)
+        if pilot == "noisy":
+            x = x + lcg_noise(len(x), 7, 0.02)
         d = oracle_mod.DemodWFM(fs)
         locks, outs = [], []
         for k in range(blocks):
@@ -413,10 +419,11 @@ def test_wfm_stereo_pilot_pll_of_the_reference_does_not_hold_lock(oracle_mod):
             locks.append(lk)
             outs.append(o)
         assert not any(locks[3:]), "pilot phase %.2f" % ph
-        assert abs(d.s.nco_freq - (-19000.0 * 2 * np.pi / fs)) < 2e-6  # the frequency IS found ...
-        assert d.s.err_ave > 1.0                                        # ... the phase detector never settles
+        if pilot == "clean":
+            assert abs(d.s.nco_freq - (-19000.0 * 2 * np.pi / fs)) < 1e-5  # the frequency IS found (to 0.6 Hz) ...
+        assert d.s.err_ave > 1.0                                            # ... the phase detector never settles
         tail = np.concatenate(outs[8:])
-        assert np.array_equal(tail.real, tail.imag)                     # mono in both channels
+        assert np.array_equal(tail.real, tail.imag)                         # mono in both channels
 
 
 def test_uncompensated_bin_power_of_a_full_scale_tone(oracle_mod):

@@ -749,6 +749,37 @@ def test_process_raw_equals_normalize_then_process(gpu_lib, oracle_mod):
         a.process_raw_device(1, n, 9)  # unknown format
 
 
+def test_process_raw_with_zero_gain_and_squelch_never_closes(gpu_lib):
+    """Two corners of the call's argument handling.  (1) pebblegpu_receiver_process_raw with gain 0 -- m_userIQGain = 0 multiplies
+    every sample by zero in the reference (deviceinterfacebase.cpp:651): silence on the route that converts in the kernels' own
+    loads (one WFM channel, 8192 bins) and on the route that stages through normalizeIQ (two streams), which once read the 0 as
+    "no scale given".  (2) set_squelch(-120) -- "never closes" -- is accepted by a WFM receiver created for several super-frames per
+    call (a threshold that could close its gate is refused there), and the receiver keeps working."""
+    import pebblesdr_amd as P
+    fs = 20_000_000
+    rng = np.random.default_rng(3)
+    for S, bins in ((1, 8192), (2, 4096)):
+        rx = P.ReceiverBank(fs if S == 1 else 2048000, S, S == 1, True, bins, max_superframes=2)
+        for c in range(S):
+            rx.set_mixer(c, 150e3)
+        rx.set_squelch(0, -120.0)
+        with pytest.raises(P.PebbleGpuError):
+            rx.set_squelch(0, -60.0)
+        n = 2 * rx.superframe
+        raw = rng.integers(-100, 100, size=(S, n, 2)).astype(np.int8)
+        buf = P.DeviceBuffer.from_array(raw, 0)
+        try:
+            rx.process_raw_device(buf.ptr, n, 0, 0, 1.0)
+            assert np.abs(rx.audio()).max() > 0
+            rx.process_raw_device(buf.ptr, n, 0, 0, 0.0)
+            rx.process_raw_device(buf.ptr, n, 0, 0, 0.0)  # (the second such call: the filters' memories have drained)
+            a, sp = rx.audio(), rx.spectrum()
+        finally:
+            buf.free()
+        assert np.abs(a[:, a.shape[1] // 2:]).max() < 1e-6
+        assert sp[:, -1].max() <= -119.9
+
+
 def test_config5_streambank_small(gpu_lib, oracle_mod):
     """3 streams x 3 calls x 2 frames of 65536: every stream has its own filter; the band-pass overlap and the
     spectrum's previous-frame average carry across calls (fastfir.cpp:312-316, fft.cpp:349-353)."""
