@@ -1710,15 +1710,32 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
     big = frame == (uint32_t)kBigN && fft_size == (uint32_t)kBigN;  // BASELINE config 5: past the fft.h:21 clamp on purpose
     if (big) bins = kBigN;
     const bool pow2_zp = nf == 2048 && (bins == 2048 || bins == 4096 || bins == 8192 || bins == 16384 || bins == 32768);
-    if (!big && !pow2_zp)
-        return fail(PEBBLEGPU_E_UNSUPPORTED, "spectrum needs 2048-sample frames and 2048/4096/8192/16384/32768 bins in this build (asked %u/%u)", nf, bins);
+    // every other frame length (settings.cpp:57) goes through the general kernel: the frame rounded up to a power of two M <= 16384,
+    // bins a power of two >= M (Accelerate's radix-2 transform takes no other sizes either)
+    {
+        int M = 256, lg = 8;
+        while ((uint32_t)M < nf) { M *= 2; lg++; }
+        int zl = 0;
+        while (((uint32_t)M << zl) < bins) zl++;
+        const bool ok = !big && M <= 16384 && ((uint32_t)M << zl) == bins && bins <= 32768;
+        any = !big && !pow2_zp;
+        if (any && !ok)
+            return fail(PEBBLEGPU_E_UNSUPPORTED, "spectrum needs frames of at most 16384 samples and a power-of-two bin count of at least the frame length, at most 32768 (asked %u/%u)", nf, bins);
+        if (ok) {
+            any_M = M; any_logM = lg; any_zp_log2 = zl;
+            std::vector<float2> tw((size_t)M / 2);
+            for (int k = 0; k < M / 2; k++) tw[k] = make_float2((float)std::cos(-design::kTwoPi * k / M), (float)std::sin(-design::kTwoPi * k / M));
+            PG_HIP(hipMalloc((void **)&d_twM, sizeof(float2) * tw.size()));
+            PG_HIP(hipMemcpy(d_twM, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+        }
+    }
     // One transform per 128-item workgroup (k_spectrum_q128) serves every power-of-two zero-padding; measured against the
     // shared-frame kernels on the bench batch it wins at 2048 bins (0.098 vs 0.105 ms) and loses at 4096 (0.198 vs 0.185) and
     // 8192 (0.44 vs 0.28: its ZP workgroups each re-read the frame and store 4-byte bins ZP*4 bytes apart), so it runs where
     // it wins and where nothing else exists (16384, 32768).  PEBBLEGPU_SPECTRUM_PERQ=1 forces it everywhere (A/B runs).
     { const char *e = getenv("PEBBLEGPU_SPECTRUM_W64"); use_w64 = e && e[0] == '1'; }  // the one-wave 8192-bin kernel (measured equal: opt-in)
     const char *env = getenv("PEBBLEGPU_SPECTRUM_PERQ");
-    per_q = !big && (bins == 2048 || bins > 8192 || (env && env[0] == '1'));
+    per_q = !big && !any && (bins == 2048 || bins > 8192 || (env && env[0] == '1'));
     std::vector<double> w;
     const double cg = design::blackman_harris(nf, w);
     std::vector<float> wf(nf);
@@ -1773,17 +1790,50 @@ int SpectrumCore::init(uint32_t streams, uint32_t frame, uint32_t fft_size)
 }
 void SpectrumCore::release()
 {
-    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128, d_ftab};
+    void *p[] = {d_window, d_btab, d_prev[0], d_prev[1], d_tw_nf, d_Y, d_btab128, d_tw128, d_ftab, d_twM};
+    d_twM = nullptr;
     for (void *q : p) if (q) (void)hipFree(q);
     d_ftab = nullptr;
     d_window = nullptr; d_btab = nullptr; d_prev[0] = d_prev[1] = nullptr; d_tw_nf = nullptr; d_Y = nullptr; d_btab128 = d_tw128 = nullptr;
     y_cap = 0;
+}
+// FFT::fftSpectrum for any frame length (and for fewer samples than samplesPerBuffer: copied, zero-padded, not windowed, fft.cpp:129-157)
+int SpectrumCore::run_any(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out, int n_in, bool windowed)
+{
+    if (!d_twM) return fail(PEBBLEGPU_E_UNSUPPORTED, "no general display transform for %u-sample frames and %u bins", nf, bins);
+    if (n_in <= 0 || n_in > any_M || (uint32_t)n_in > nf) return fail(PEBBLEGPU_E_SIZE, "%d samples do not fit a frame of %u", n_in, nf);
+    if (F == 0) return 0;
+    SpectrumParams sp;
+    sp.in_pitch = in_pitch;
+    sp.n_frames = F;
+    const int zp = 1 << any_zp_log2;
+    long long G = (F * (long long)S * zp) / 1024;  // every chain recomputes one frame: chains as long as leaves about a thousand workgroups
+    G = G < 1 ? 1 : (G > 32 ? 32 : G);
+    sp.frames_per_group = (int)G;
+    sp.scale = scale;
+    sp.out_pitch = F * (long long)bins;
+    AnySpecParams ap;
+    ap.n_in = n_in;
+    ap.frame = (int)nf;
+    ap.M = any_M;
+    ap.logM = any_logM;
+    ap.zp_log2 = any_zp_log2;
+    ap.windowed = windowed ? 1 : 0;
+    launch_lds(k_spectrum_any, dim3((unsigned)(cdiv(F, G) * zp), S), dim3(256), sizeof(float2) * (size_t)any_M, s, d_in, d_out, (const float *)d_window, (const float2 *)d_twM,
+               (const float *)d_prev[parity], d_prev[parity ^ 1], sp, ap);
+    parity ^= 1;
+    PG_HIP(hipGetLastError());
+    return 0;
 }
 int SpectrumCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, long long F, float *d_out, const RawSrc *raw, const DecFuse *df, bool nothing_beside)
 {
     if (df && !dec_ready()) return fail(PEBBLEGPU_E_INVALID, "the decimator was handed to a display transform that cannot run it");
     last_fullc = nothing_beside && !df && dec_ready();
     if (raw && !raw_ready()) return fail(PEBBLEGPU_E_INVALID, "raw-format input reached a spectrum kernel that has no converting loads");
+    if (any) {
+        if (raw || df) return fail(PEBBLEGPU_E_INVALID, "the general display transform takes float2 input and runs no decimator");
+        return run_any(s, d_in, in_pitch, F, d_out, (int)nf, true);
+    }
     SpectrumParams sp;
     sp.in_pitch = in_pitch;
     sp.n_frames = F;

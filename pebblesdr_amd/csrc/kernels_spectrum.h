@@ -1196,6 +1196,92 @@ static __global__ __launch_bounds__(256, 2) void k_big256_rows(const float2 *__r
 // SIMD -- and measured slower, 0.39 ms against 0.32 for the bench shard: its rows wait on workgroup-wide barriers and on their
 // own loads, where here every wave runs alone.)
 // ------------------------------------------------------------------------------------------------
+// Any other frame length: FFT::fftSpectrum for framesPerBuffer != 2048 (settings.cpp:57 makes it a setting) and for the branch of
+// m_applyWindow that takes fewer samples than samplesPerBuffer -- copied, zero-padded, NOT windowed (fft.cpp:129-157).  Functional
+// path, not the bench's: one (frame chain, q) per 256-item workgroup, the pruned zero-padded transform as bins / M transforms of M =
+// the frame length rounded up to a power of two (<= 16384: 128 KiB of LDS), each a plain radix-2 decimation-in-time transform in LDS
+// (bit-reversed load, log2 M passes, twiddles W_M^k from a table), previous-frame amplitudes carried in registers along the chain.
+//   X[ZP k + q] = sum_{n < n_in} (w[n] x[n] W_bins^{n q}) W_M^{n k}
+// grid (chains * ZP, S), block 256, dynamic LDS M * 8 bytes.
+// ------------------------------------------------------------------------------------------------
+struct AnySpecParams {
+    int n_in;        // samples taken from every frame (== frame length, or fewer: the un-windowed branch)
+    int frame;       // samples from one frame to the next in the input
+    int M, logM;     // transform length and its log2
+    int zp_log2;     // bins = M << zp_log2
+    int windowed;    // multiply by window[n] (numSamples == samplesPerBuffer)
+};
+static __global__ __launch_bounds__(256) void k_spectrum_any(const float2 *__restrict__ in, float *__restrict__ out, const float *__restrict__ window,
+                                                            const float2 *__restrict__ twM, const float *__restrict__ prev_in, float *__restrict__ prev_out,
+                                                            SpectrumParams sp, AnySpecParams ap)
+{
+    HIP_DYNAMIC_SHARED(float2, buf)
+    constexpr int EMAX = 64;  // M / 256 <= 64 points per work-item
+    const int tid = threadIdx.x, s = blockIdx.y;
+    const int ZP = 1 << ap.zp_log2, q = blockIdx.x & (ZP - 1);
+    const int M = ap.M, logM = ap.logM, bins = M << ap.zp_log2;
+    const int E = M >= 256 ? M >> 8 : 1;
+    const int G = sp.frames_per_group;
+    const long long f0 = (long long)(blockIdx.x >> ap.zp_log2) * G;
+    const float db_off = 6.02059991327962f * __builtin_amdgcn_logf(0.5f * sp.scale);
+    float pa[EMAX];
+#pragma unroll
+    for (int m = 0; m < EMAX; m++) pa[m] = 0.f;
+    for (int it = -1; it < G; it++) {
+        const long long f = f0 + it;
+        if (f >= sp.n_frames) break;  // (uniform)
+        if (f < 0) {
+#pragma unroll
+            for (int m = 0; m < EMAX; m++)
+                if (m < E && tid + 256 * m < M) pa[m] = prev_in[(long long)s * bins + ((tid + 256 * m) << ap.zp_log2) + q];
+            continue;
+        }
+        const float2 *x = in + (long long)s * sp.in_pitch + f * ap.frame;
+        for (int i = tid; i < M; i += 256) {
+            float2 v = make_float2(0.f, 0.f);
+            if (i < ap.n_in) {
+                v = x[i];
+                if (ap.windowed) v = cscale(v, window[i]);
+                if (q) v = cmul(cis_cycles(-(double)(((long long)i * q) & (bins - 1)) / (double)bins), v);
+            }
+            buf[__brev((unsigned)i) >> (32 - logM)] = v;
+        }
+        __syncthreads();
+        for (int st = 1; st <= logM; st++) {
+            const int half = 1 << (st - 1);
+            for (int b = tid; b < (M >> 1); b += 256) {
+                const int j = b & (half - 1), i0 = ((b >> (st - 1)) << st) + j, i1 = i0 + half;
+                const float2 t = cmul(twM[j << (logM - st)], buf[i1]), a = buf[i0];
+                buf[i0] = cadd(a, t);
+                buf[i1] = csub(a, t);
+            }
+            __syncthreads();
+        }
+        float *yf = out + (long long)s * sp.out_pitch + f * (long long)bins;
+#pragma unroll
+        for (int m = 0; m < EMAX; m++) {
+            const int k = tid + 256 * m;
+            if (m < E && k < M) {
+                const float2 z = buf[k];
+                const float mag = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
+                const float a = mag + pa[m];
+                pa[m] = mag;
+                if (it >= 0) {
+                    const int u = (((k << ap.zp_log2) + q) + (bins >> 1)) & (bins - 1);  // unfold, fft.cpp:207-213
+                    yf[u] = fminf(fmaxf(fmaf(6.02059991327962f, __builtin_amdgcn_logf(a), db_off), -120.f), 0.f);
+                }
+            }
+        }
+        if (f == sp.n_frames - 1) {
+#pragma unroll
+            for (int m = 0; m < EMAX; m++)
+                if (m < E && tid + 256 * m < M) prev_out[(long long)s * bins + ((tid + 256 * m) << ap.zp_log2) + q] = pa[m];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // SignalStrength::fdEstimate (application/signalstrength.cpp:287-380) on every frame of the unprocessed spectrum: peak and
 // average power inside the band-pass window around the mixer frequency, average power of one window width either side
 // (noise), all from the dB bins (power = 10^(dB/10)).  One wave per (frame, channel); out[channel][frame] =

@@ -342,6 +342,11 @@ struct SpectrumCore {
     size_t y_cap = 0;
     float scale = 0;
     int parity = 0;
+    // any other frame length, and frames shorter than samplesPerBuffer (un-windowed): k_spectrum_any
+    bool any = false;                 // the frame length / bin count has none of the kernels above: every call takes the general kernel
+    int any_M = 0, any_logM = 0, any_zp_log2 = 0;
+    float2 *d_twM = nullptr;          // W_M^k, k < M / 2
+    int run_any(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, int n_in, bool windowed);
     int init(uint32_t streams, uint32_t frame, uint32_t fft_size);
     void release();
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, long long n_frames, float *d_out, const RawSrc *raw = nullptr, const DecFuse *df = nullptr, bool nothing_beside = false);

@@ -82,6 +82,7 @@ struct pebblegpu_spectrum : pg::StepBase {
     float2 *d_in = nullptr;
     float *d_out = nullptr;
     std::vector<float> hs;
+    int path = 0;  // 0: no call yet; 1: the frame-length kernels; 2: the general kernel (their previous-frame amplitudes are laid out differently)
 };
 
 extern "C" {
@@ -407,13 +408,22 @@ int pebblegpu_spectrum_bins(const pebblegpu_spectrum *s, uint32_t *bins)
 int pebblegpu_spectrum_process(pebblegpu_spectrum *s, const double *in, int n, double *out_db, int *overload)
 {
     if (!s || !in || !out_db) return fail(PEBBLEGPU_E_INVALID, "null argument");
-    if ((uint32_t)n != s->sp.nf)
-        return fail(PEBBLEGPU_E_UNSUPPORTED, "only the windowed case numSamples == samplesPerBuffer (%u) is built (fft.cpp:132)", s->sp.nf);
+    if (n <= 0 || (uint32_t)n > s->sp.nf)
+        return fail(PEBBLEGPU_E_SIZE, "numSamples %d is not in 1..samplesPerBuffer (%u)", n, s->sp.nf);
     PG_HIP(hipSetDevice(s->device));
     int ov = 0;  // m_isOverload: any |re| or |im| above m_overLimit = 0.9 (fft.cpp:137-140), flagged on the host copy
     for (int i = 0; i < 2 * n; i++) if (std::fabs(in[i]) > 0.9) { ov = 1; break; }
     if (int rc = s->up(s->d_in, in, (size_t)n)) return rc;
-    if (int rc = s->sp.run(s->stream, s->d_in, n, 1, s->d_out, nullptr, nullptr, true)) return rc;  // (a step on its own stream: nothing beside it)
+    const int path = ((uint32_t)n == s->sp.nf && !s->sp.any) ? 1 : 2;
+    if (s->path && s->path != path)
+        return fail(PEBBLEGPU_E_UNSUPPORTED, "one spectrum object takes either whole buffers of %u samples or shorter ones (its previous-frame average is kept per kernel family): create a second object", s->sp.nf);
+    s->path = path;
+    if ((uint32_t)n == s->sp.nf) {
+        if (int rc = s->sp.run(s->stream, s->d_in, n, 1, s->d_out, nullptr, nullptr, true)) return rc;  // (a step on its own stream: nothing beside it)
+    } else {
+        // fewer samples than samplesPerBuffer: copied, zero-padded, not windowed (fft.cpp:129-157)
+        if (int rc = s->sp.run_any(s->stream, s->d_in, n, 1, s->d_out, n, false)) return rc;
+    }
     PG_HIP(hipStreamSynchronize(s->stream));
     s->hs.resize(s->sp.bins);
     PG_HIP(hipMemcpy(s->hs.data(), s->d_out, sizeof(float) * s->sp.bins, hipMemcpyDeviceToHost));

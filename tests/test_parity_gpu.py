@@ -348,6 +348,80 @@ def test_spectrum_step(gpu_lib, oracle_mod, bins):
     assert ov  # m_overLimit = 0.9, fft.cpp:137-140
 
 
+@pytest.mark.parametrize("nf,bins", [(1024, 2048), (1024, 8192), (4096, 4096), (4096, 16384), (8192, 8192), (8192, 32768), (16384, 16384), (16384, 32768),
+                                     (3000, 4096)])
+def test_spectrum_step_for_other_frame_lengths(gpu_lib, oracle_mod, nf, bins):
+    """FFT::fftSpectrum for framesPerBuffer != 2048 (a setting, settings.cpp:57; 3000: not a power of two): window of the frame's
+    length, zero-padding to the bin count, unfold, previous-frame average, dB -- five frames against the oracle."""
+    import pebblesdr_amd as P
+    fs = 2.048e6
+    x = tones(fs, 5 * nf, [(10 ** (-10 / 20), 123456.7), (10 ** (-40 / 20), -700001.3)]) + lcg_noise(5 * nf, 1, 1e-4)
+    ref = oracle_mod.Spectrum(bins, nf)
+    sp = P.Spectrum(bins, fs, nf)
+    assert sp.bins == bins
+    for f in range(5):
+        fr = x[f * nf:(f + 1) * nf]
+        r = ref.process(fr)
+        g, ov = sp.fftSpectrum(fr)
+        assert not ov
+        if f:
+            assert db_err(g, r) <= TOL_DB, f
+        assert g.min() >= -120.0 and g.max() <= 0.0
+
+
+@pytest.mark.parametrize("nf,bins,n", [(2048, 4096, 1500), (2048, 2048, 2047), (4096, 8192, 1024), (1024, 2048, 1000)])
+def test_spectrum_step_with_fewer_samples_than_the_buffer(gpu_lib, oracle_mod, nf, bins, n):
+    """The other branch of FFT::m_applyWindow (fft.cpp:129-157): numSamples != samplesPerBuffer copies the samples, zero-pads
+    and applies NO window (the scale still divides by the window's coherent gain).  Four calls of n samples against the oracle;
+    a spectrum object serves whole buffers or short ones, not both (its previous-frame average is kept per kernel family)."""
+    import pebblesdr_amd as P
+    fs = 2.048e6
+    x = tones(fs, 4 * n, [(10 ** (-10 / 20), 123456.7), (10 ** (-40 / 20), -700001.3)]) + lcg_noise(4 * n, 2, 1e-4)
+    ref = oracle_mod.Spectrum(bins, nf)
+    sp = P.Spectrum(bins, fs, nf)
+    for f in range(4):
+        fr = x[f * n:(f + 1) * n]
+        r = ref.process(fr)
+        g, _ = sp.fftSpectrum(fr)
+        if f:
+            assert db_err(g, r) <= TOL_DB, f
+    if nf == 2048:
+        with pytest.raises(P.PebbleGpuError):
+            sp.fftSpectrum(x[:nf])  # the same object with a whole buffer: refused, loudly
+
+
+def test_receiver_with_4096_sample_frames(gpu_lib, oracle_mod):
+    """A receiver created with framesPerBuffer = 4096 (settings.cpp:57): the display transform of every 4096-sample frame at 8192
+    bins and the AM chain, against an oracle receiver of the same frame length."""
+    import pebblesdr_amd as P
+    fs, n, bins = 2048000, 4096, 8192
+    rx = P.ReceiverBank(fs, 1, True, False, bins, frames_per_buffer=n, max_superframes=1)
+    rx.set_mode(0, P.DM_AM); rx.set_mixer(0, 100e3); rx.set_bandpass(0, -5000, 5000)
+    sf = rx.superframe
+    t = np.arange(2 * sf) / fs
+    x = 0.3 * (1 + 0.5 * np.cos(2 * np.pi * 1000 * t)) * np.exp(2j * np.pi * 100e3 * t) + lcg_noise(2 * sf, 9, 1e-3)
+    ref = oracle_mod.Receiver(fs, n, bins)
+    ref.set_mode(oracle_mod.AM); ref.set_mixer(100e3); ref.set_filter(-5000, 5000)
+    ra, rs = [], []
+    for f in range(2 * sf // n):
+        a, sp_ = ref.process(x[f * n:(f + 1) * n])
+        if a is not None and len(a):
+            ra.append(a)
+        rs.append(sp_)
+    ra = np.concatenate(ra)
+    ga, gs = [], []
+    for k in range(2):
+        a, sp_ = rx.process(x[k * sf:(k + 1) * sf])
+        ga.append(a[0]); gs.append(sp_[0])
+    ga = np.concatenate(ga); gs = np.concatenate(gs)
+    assert gs.shape == (2 * sf // n, bins)
+    for f in range(1, gs.shape[0]):
+        assert db_err(gs[f], rs[f]) <= TOL_DB, f
+    assert ra.shape == ga.shape
+    for k in range(len(ga) // n):
+        assert rel_rms(ga[k * n:(k + 1) * n], ra[k * n:(k + 1) * n]) <= TOL, k
+
+
 def test_spectrum_known_answer_on_device(gpu_lib):
     """The reference's own table (fft.cpp:363-369) straight from the device: -10 dB tone at 48 kHz / 1 Msps."""
     import pebblesdr_amd as P
