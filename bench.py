@@ -409,10 +409,32 @@ def pcie_inclusive(P, rx, n, device):
     f_float()
     f_raw()
     a, b = best(f_float), best(f_raw)
+    # the same int8 batches through the library's pinned double buffer (pebblegpu_receiver_ingest_*): the upload of the next batch
+    # crosses PCIe on a copy stream while this one computes and its audio is read.  (A device plugin writes its samples straight into
+    # the slots; here both are filled once, outside the timed loop.)
+    for slot in (0, 1):
+        rx.ingest_buffer(slot, raw.nbytes)[:] = raw
+    rx.ingest_submit(0, raw.nbytes)
+    k_steps = 6
+
+    def pipelined():
+        for k in range(k_steps):
+            s = k & 1
+            rx.process_ingested(s, n, 0, 0, 1.0)
+            rx.ingest_buffer(s ^ 1, raw.nbytes)   # (blocks until the other slot's last call is over: it is)
+            rx.ingest_submit(s ^ 1, raw.nbytes)   # the next batch travels while this call computes
+            rx.audio()
+    pipelined()
+    t0 = time.perf_counter()
+    pipelined()
+    c = (time.perf_counter() - t0) / k_steps
+    rx.synchronize()
     dbuf.free()
     rbuf.free()
     return {"float2_in_audio_out": {"ms": round(a * 1e3, 3), "Msamples_per_s": round(n / a / 1e6, 1)},
             "int8_in_audio_out": {"ms": round(b * 1e3, 3), "Msamples_per_s": round(n / b / 1e6, 1)},
+            "int8_pinned_double_buffered_audio_out": {"ms": round(c * 1e3, 3), "Msamples_per_s": round(n / c / 1e6, 1),
+                                                      "how": "pebblegpu_receiver_ingest_acquire / _submit / process_ingested, two pinned slots, %d batches back to back" % k_steps},
             "note": "pageable host memory, hipMemcpy each way, spectra left on the device"}
 
 

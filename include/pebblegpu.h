@@ -177,6 +177,20 @@ int pebblegpu_receiver_process(pebblegpu_receiver *rx, const void *d_iq, uint64_
  * buffer on the library's stream (no host synchronisation) and processed as above.  Moves 2-4 bytes per sample over
  * PCIe/HBM on the way in instead of 8. */
 int pebblegpu_receiver_process_raw(pebblegpu_receiver *rx, int format, int iq_order, double gain, const void *d_raw, uint64_t n_samples);
+/* Host ingest through the library's own pinned buffers (the device plugins' producer side, e.g. the HackRF callback that fills
+ * the producer/consumer ring, plugins/HackRFDevice/hackrfdevice.cpp:533-566, writes its raw samples straight into one): two slots,
+ * so that the upload of one batch crosses PCIe on a copy stream while the call on the other batch computes.
+ *   acquire  -- the slot's pinned host buffer of at least `bytes` (grown on demand); blocks until the last call that read the slot
+ *               is over, then the host may fill it.  The pointer stays valid until the next acquire of that slot with a larger size.
+ *   submit   -- queues the upload of the first `bytes` of the slot (returns at once; the host must not touch the slot until it
+ *               has acquired it again);
+ *   process_ingested -- pebblegpu_receiver_process_raw on the uploaded samples, ordered behind the upload on the device (no host
+ *               synchronisation).  n_streams x n_samples pairs of `format` must have been submitted.
+ * Steady state of a producer: acquire(s), fill, submit(s), process_ingested(s), s ^= 1 -- with the audio of the previous call read
+ * in between.  The PCIe link bounds this path (2 bytes per sample for HackRF/RTL pairs); DESIGN.md section 5 has the measured rates. */
+int pebblegpu_receiver_ingest_acquire(pebblegpu_receiver *rx, uint32_t slot, uint64_t bytes, void **host_ptr);
+int pebblegpu_receiver_ingest_submit(pebblegpu_receiver *rx, uint32_t slot, uint64_t bytes);
+int pebblegpu_receiver_process_ingested(pebblegpu_receiver *rx, uint32_t slot, int format, int iq_order, double gain, uint64_t n_samples);
 /* returns channel 0's row; channel c starts *pitch_samples float2 further per channel */
 const void *pebblegpu_receiver_audio(const pebblegpu_receiver *rx, uint64_t *samples_per_channel, uint64_t *pitch_samples);
 const void *pebblegpu_receiver_spectrum(const pebblegpu_receiver *rx, uint64_t *frames_per_stream);

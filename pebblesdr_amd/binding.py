@@ -17,7 +17,7 @@ SYMBOLS = [
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
     "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch", "pebblegpu_receiver_process_raw",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum", "pebblegpu_receiver_zoom_spectrum",
-    "pebblegpu_receiver_last_ms", "pebblegpu_receiver_kernel_name", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
+    "pebblegpu_receiver_ingest_acquire", "pebblegpu_receiver_ingest_submit", "pebblegpu_receiver_process_ingested", "pebblegpu_receiver_last_ms", "pebblegpu_receiver_kernel_name", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
     "pebblegpu_streambank_process", "pebblegpu_streambank_filtered", "pebblegpu_streambank_spectrum",
     "pebblegpu_streambank_last_ms", "pebblegpu_streambank_synchronize",
@@ -104,6 +104,9 @@ def _declare(L):
     L.pebblegpu_receiver_last_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_mean_ms.argtypes = [vp, i32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_receiver_set_profiling.argtypes = [vp, i32]
+    L.pebblegpu_receiver_ingest_acquire.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.pebblegpu_receiver_ingest_submit.argtypes = [vp, C.c_uint32, C.c_uint64]
+    L.pebblegpu_receiver_process_ingested.argtypes = [vp, C.c_uint32, i32, i32, C.c_double, C.c_uint64]
     L.pebblegpu_receiver_kernel_name.restype = C.c_char_p
     L.pebblegpu_receiver_kernel_name.argtypes = [vp, i32]
     L.pebblegpu_receiver_enable_signal_strength.argtypes = [vp, i32]
@@ -314,6 +317,19 @@ class ReceiverBank:
     def process_raw_device(self, dptr, n_samples, fmt, iq_order=0, gain=1.0):
         """raw device-format IQ pairs (pebblegpu_iq_format) already on the device -> normalizeIQ + the full call"""
         check(self.L, self.L.pebblegpu_receiver_process_raw(self.h, int(fmt), int(iq_order), float(gain), C.c_void_p(dptr), int(n_samples)))
+
+    def ingest_buffer(self, slot, nbytes, dtype=np.int8):
+        """the slot's pinned host buffer as a numpy array (valid until the slot is acquired again with a larger size)"""
+        p = C.c_void_p()
+        check(self.L, self.L.pebblegpu_receiver_ingest_acquire(self.h, int(slot), int(nbytes), C.byref(p)))
+        n = int(nbytes) // np.dtype(dtype).itemsize
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,))
+
+    def ingest_submit(self, slot, nbytes):
+        check(self.L, self.L.pebblegpu_receiver_ingest_submit(self.h, int(slot), int(nbytes)))
+
+    def process_ingested(self, slot, n_samples, fmt, iq_order=0, gain=1.0):
+        check(self.L, self.L.pebblegpu_receiver_process_ingested(self.h, int(slot), int(fmt), int(iq_order), float(gain), int(n_samples)))
 
     def synchronize(self):
         check(self.L, self.L.pebblegpu_receiver_synchronize(self.h))

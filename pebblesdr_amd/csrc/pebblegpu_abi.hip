@@ -179,6 +179,21 @@ int pebblegpu_receiver_process_raw(pebblegpu_receiver *h, int format, int iq_ord
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
     return h->rx.process_raw(format, iq_order, gain, d_raw, n_samples);
 }
+int pebblegpu_receiver_ingest_acquire(pebblegpu_receiver *h, uint32_t slot, uint64_t bytes, void **host_ptr)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.ingest_acquire(slot, bytes, host_ptr);
+}
+int pebblegpu_receiver_ingest_submit(pebblegpu_receiver *h, uint32_t slot, uint64_t bytes)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.ingest_submit(slot, bytes);
+}
+int pebblegpu_receiver_process_ingested(pebblegpu_receiver *h, uint32_t slot, int format, int iq_order, double gain, uint64_t n_samples)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.process_ingested(slot, format, iq_order, gain, n_samples);
+}
 const void *pebblegpu_receiver_audio(const pebblegpu_receiver *h, uint64_t *samples_per_channel, uint64_t *pitch_samples)
 {
     if (!h) return nullptr;

@@ -379,6 +379,11 @@ public:
     int set_conditioners(uint32_t stream, int flags, double iq_gain, double iq_phase);
     int set_noise_filter(uint32_t ch, bool on);
     int process_raw(int fmt, int order, double gain, const void *d_raw, uint64_t n);  // normalizeIQ on the library's stream, then process()
+    // host ingest through library-owned pinned buffers (two slots): the device plugin writes its raw samples into a slot, the upload
+    // of one slot travels on a copy stream while the call on the other computes
+    int ingest_acquire(uint32_t slot, uint64_t bytes, void **host_ptr);
+    int ingest_submit(uint32_t slot, uint64_t bytes);
+    int process_ingested(uint32_t slot, int fmt, int order, double gain, uint64_t n);
     int set_squelch(uint32_t ch, double squelch_db);   // Receiver::squelchChanged, receiver.cpp:704-707
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain, const RawSrc *raw = nullptr);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
@@ -460,6 +465,13 @@ private:
     SpectrumCore spec_, zoom_;
     float2 *d_stage_in_ = nullptr;
     float2 *d_raw_stage_ = nullptr;   // process_raw: the normalised copy of a raw device-format call (allocated on first use)
+    struct IngestSlot {
+        void *h = nullptr, *d = nullptr;      // pinned host buffer and its device twin
+        size_t cap = 0, submitted = 0;
+        hipEvent_t uploaded = nullptr, done_main = nullptr, done_chain = nullptr;
+        bool in_flight = false;               // a call that reads the device twin has been queued and not waited for
+    } ingest_[2];
+    hipStream_t copy_stream_ = nullptr;
     std::vector<float> h_frame_, h_out_;
     uint64_t acc_frames_ = 0;
 };

@@ -98,6 +98,12 @@ Receiver::~Receiver()
     if (chain_stream_) (void)hipStreamSynchronize(chain_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release(); zoom_.release();
+    if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+    for (IngestSlot &g : ingest_) {
+        if (g.h) (void)hipHostFree(g.h);
+        if (g.d) (void)hipFree(g.d);
+        for (hipEvent_t e : {g.uploaded, g.done_main, g.done_chain}) if (e) (void)hipEventDestroy(e);
+    }
     if (d_zoom) (void)hipFree(d_zoom);
     agc_.release(); resamp_.release(); cond_.release(); anf_.release();
     if (d_audio_rs) (void)hipFree(d_audio_rs);
@@ -557,6 +563,68 @@ int Receiver::process_raw(int fmt, int order, double gain, const void *d_raw, ui
     else if (fmt == 4) scale *= 1 / 32767.0;             // wavfile.cpp:299-300
     const RawSrc raw{d_raw, fmt, order, (float)scale, 0};
     return process(nullptr, n, bins != 0, true, &raw);
+}
+
+// ---- host ingest: pinned double buffer (the library owns the pinned host buffers; the producer side of
+// plugins/HackRFDevice/hackrfdevice.cpp:533-566 writes into them instead of into its own ring) ----
+int Receiver::ingest_acquire(uint32_t slot, uint64_t bytes, void **host_ptr)
+{
+    if (slot > 1 || !host_ptr || bytes == 0) return fail(PEBBLEGPU_E_INVALID, "ingest slot is 0 or 1, bytes > 0");
+    PG_HIP(hipSetDevice(device));
+    IngestSlot &g = ingest_[slot];
+    if (g.in_flight) {  // the call that read this slot's device copy (and the upload before it) must be over before the host refills it
+        PG_HIP(hipEventSynchronize(g.done_main));
+        PG_HIP(hipEventSynchronize(g.done_chain));
+        g.in_flight = false;
+    }
+    if (!copy_stream_) PG_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if (!g.uploaded) {
+        PG_HIP(hipEventCreateWithFlags(&g.uploaded, hipEventDisableTiming));
+        PG_HIP(hipEventCreateWithFlags(&g.done_main, hipEventDisableTiming));
+        PG_HIP(hipEventCreateWithFlags(&g.done_chain, hipEventDisableTiming));
+    }
+    if (g.cap < bytes) {
+        PG_HIP(hipStreamSynchronize(copy_stream_));
+        if (g.h) (void)hipHostFree(g.h);
+        if (g.d) (void)hipFree(g.d);
+        g.h = g.d = nullptr;
+        g.cap = 0;
+        PG_HIP(hipHostMalloc(&g.h, bytes));
+        PG_HIP(hipMalloc(&g.d, bytes));
+        g.cap = bytes;
+    }
+    g.submitted = 0;
+    *host_ptr = g.h;
+    return 0;
+}
+int Receiver::ingest_submit(uint32_t slot, uint64_t bytes)
+{
+    if (slot > 1) return fail(PEBBLEGPU_E_INVALID, "ingest slot is 0 or 1");
+    IngestSlot &g = ingest_[slot];
+    if (!g.h || bytes == 0 || bytes > g.cap) return fail(PEBBLEGPU_E_SIZE, "%llu bytes do not fit the slot acquired (%zu)", (unsigned long long)bytes, g.cap);
+    if (g.in_flight) return fail(PEBBLEGPU_E_INVALID, "the slot's previous call is still in flight: acquire it again first");
+    PG_HIP(hipSetDevice(device));
+    PG_HIP(hipMemcpyAsync(g.d, g.h, bytes, hipMemcpyHostToDevice, copy_stream_));
+    PG_HIP(hipEventRecord(g.uploaded, copy_stream_));
+    g.submitted = bytes;
+    return 0;
+}
+int Receiver::process_ingested(uint32_t slot, int fmt, int order, double gain, uint64_t n)
+{
+    if (slot > 1) return fail(PEBBLEGPU_E_INVALID, "ingest slot is 0 or 1");
+    IngestSlot &g = ingest_[slot];
+    if (fmt < 0 || fmt > 4) return fail(PEBBLEGPU_E_INVALID, "unknown sample format %d", fmt);
+    static const size_t kPair[5] = {2, 2, 4, 8, 4};  // bytes per IQ pair: CPX8, CPXU8, CPX16, CPXFLOAT, WAV PCM16
+    if (!g.submitted || (uint64_t)S * n * kPair[fmt] > g.submitted) return fail(PEBBLEGPU_E_SIZE, "the slot holds %zu submitted bytes; %llu samples of this format need more", g.submitted, (unsigned long long)n);
+    PG_HIP(hipSetDevice(device));
+    // both of the call's streams read the raw samples (the display transform and the chain's first stage convert in their own loads)
+    PG_HIP(hipStreamWaitEvent(stream_, g.uploaded, 0));
+    PG_HIP(hipStreamWaitEvent(chain_stream_, g.uploaded, 0));
+    if (int rc = process_raw(fmt, order, gain, g.d, n)) return rc;
+    PG_HIP(hipEventRecord(g.done_main, stream_));
+    PG_HIP(hipEventRecord(g.done_chain, chain_stream_));
+    g.in_flight = true;
+    return 0;
 }
 
 const char *Receiver::kernel_name(int which) const

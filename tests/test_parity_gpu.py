@@ -823,6 +823,63 @@ def test_process_raw_equals_normalize_then_process(gpu_lib, oracle_mod):
         a.process_raw_device(1, n, 9)  # unknown format
 
 
+def test_pinned_ingest_slots_equal_process_raw(gpu_lib):
+    """pebblegpu_receiver_ingest_acquire / _submit / pebblegpu_receiver_process_ingested (the library's pinned double buffer, SURVEY 8b:
+    the producer of hackrfdevice.cpp:533-566 fills the slot instead of its own ring): six batches of HackRF int8 pairs at the
+    headline shape alternate through the two slots -- each next slot filled and submitted while the previous call is still queued --
+    and must leave bit for bit the audio and spectra a twin receiver leaves that is handed the same batches from a device buffer.
+    A slot is refused for a second submit while its call is in flight, for more bytes than were acquired, and for a format whose
+    pairs do not fit what was submitted."""
+    import pebblesdr_amd as P
+    fs, bins = 20_000_000, 8192
+    a = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
+    b = P.ReceiverBank(fs, 1, True, True, bins, max_superframes=4)
+    for rx in (a, b):
+        rx.set_mixer(0, 150e3)
+    n = 4 * a.superframe
+    rng = np.random.default_rng(11)
+    t = np.arange(n) / fs
+    batches = []
+    for k in range(6):
+        sig = 90.0 * np.exp(1j * (2 * np.pi * 150e3 * t + 10.0 * np.sin(2 * np.pi * (800 + 100 * k) * t)))
+        raw = np.empty((n, 2), dtype=np.int8)
+        raw[:, 0] = np.round(sig.real + rng.uniform(-2, 2, n)).astype(np.int8)
+        raw[:, 1] = np.round(sig.imag + rng.uniform(-2, 2, n)).astype(np.int8)
+        batches.append(raw)
+    h = a.ingest_buffer(0, 2 * n)
+    h[:] = batches[0].reshape(-1)
+    a.ingest_submit(0, 2 * n)
+    got = []
+    for k in range(6):
+        s = k & 1
+        a.process_ingested(s, n, 0, 0, 1.0)
+        with pytest.raises(P.PebbleGpuError):
+            a.ingest_submit(s, 2 * n)  # in flight
+        if k + 1 < 6:
+            h = a.ingest_buffer(s ^ 1, 2 * n)  # waits for call k-1 only; call k is still queued or running
+            h[:] = batches[k + 1].reshape(-1)
+            a.ingest_submit(s ^ 1, 2 * n)
+        got.append((a.audio(), a.spectrum()))
+    for k in range(6):
+        buf = P.DeviceBuffer.from_array(batches[k], 0)
+        try:
+            b.process_raw_device(buf.ptr, n, 0, 0, 1.0)
+            wa, ws = b.audio(), b.spectrum()
+        finally:
+            buf.free()
+        assert np.abs(wa).max() > 1e-3
+        assert np.array_equal(got[k][0], wa), k
+        assert np.array_equal(got[k][1], ws), k
+    h = a.ingest_buffer(0, 2 * n)
+    with pytest.raises(P.PebbleGpuError):
+        a.ingest_submit(0, 2 * n + 2)  # more than was acquired
+    a.ingest_submit(0, 2 * n)
+    with pytest.raises(P.PebbleGpuError):
+        a.process_ingested(0, n, 2, 0, 1.0)  # int16 pairs need twice the bytes
+    with pytest.raises(P.PebbleGpuError):
+        a.ingest_buffer(2, 16)
+
+
 def test_process_raw_with_zero_gain_and_squelch_never_closes(gpu_lib):
     """Two corners of the call's argument handling.  (1) pebblegpu_receiver_process_raw with gain 0 -- m_userIQGain = 0 multiplies
     every sample by zero in the reference (deviceinterfacebase.cpp:651): silence on the route that converts in the kernels' own
