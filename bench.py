@@ -103,7 +103,7 @@ def pmc_traffic(superframes):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
     separate runs, gfx950 half-count correction calibrated on known-size copies): tools/pmc_workload.py +
     tools/parse_traffic.py.  Only valid for the batch size it was measured on (256 super-frames)."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic_head.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if superframes != 256 or not os.path.exists(path):
             continue
@@ -112,6 +112,35 @@ def pmc_traffic(superframes):
         except Exception:
             continue
     return None, None
+
+
+def attach_measured_traffic(ks, roof, files):
+    """HBM bytes per launch from the committed PMC passes of the same geometry (tools/profile_round.sh: tools/pmc_bank.py 2|3,
+    tools/pmc_streambank.py; FETCH_SIZE and WRITE_SIZE in separate runs, parsed by tools/parse_traffic.py) onto the per-kernel lines
+    and the dominant kernel's roofline.  A label naming two launches ("a + b") gets the sum of both."""
+    for name in files:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            meas = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+
+        def total(label):
+            parts = [p.strip().split("<")[0].split(" ")[0] for p in label.split(" + ")]
+            if not all(p in meas for p in parts):
+                return None
+            return int(round(sum(meas[p]["hbm_bytes"] for p in parts)))
+        hit = False
+        for kn, v in ks.items():
+            t = total(kn)
+            if t is not None:
+                v["hbm_bytes_measured"] = t
+                hit = True
+        if roof is not None and total(roof["kernel"]) is not None:
+            roof["traffic"] = total(roof["kernel"])
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, not collected in this run)" % name
+        if hit:
+            return
 
 
 def socket_power(step, sync, seconds=2.5):
@@ -282,19 +311,10 @@ def run_bank(P, name, fs, C, modes, k, rank, world, device, barrier, args, dist)
     groups = [(names[2], ms[2], front_b), (names[3], ms[3], rest_b), (names[4], ms[4], 16 * C * n // D),
               ("AM demod: k_iir_scan + k_fir_dec" if n_am else "", ms[5], 16 * n_am * n // D)]
     ks, roof = kernel_lines(groups)
-    if roof is not None and (fs, C, k) == (2048000, 256, 8):
-        # configs[2] exactly as the committed PMC passes ran it (tools/pmc_bank.py 2): measured HBM bytes per launch
-        path = os.path.join(ROOT, "profiles", "r02_traffic_configs2.json")
-        try:
-            meas = json.load(open(path))["kernels"]
-            for kn, v in ks.items():
-                if kn in meas:
-                    v["hbm_bytes_measured"] = int(round(meas[kn]["hbm_bytes"]))
-            if roof["kernel"] in meas:
-                roof["traffic"] = int(round(meas[roof["kernel"]]["hbm_bytes"]))
-                roof["traffic_source"] = "profiles/r02_traffic_configs2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload, not collected in this run)"
-        except Exception:
-            pass
+    if (fs, C, k) == (2048000, 256, 8):  # configs[2] exactly as the committed PMC passes ran it (tools/pmc_bank.py 2)
+        attach_measured_traffic(ks, roof, ("r03_traffic_configs2.json", "r02_traffic_configs2.json"))
+    elif (fs, C, k) == (100000000, 512, 1):  # the configs[3] shard (tools/pmc_bank.py 3)
+        attach_measured_traffic(ks, roof, ("r03_traffic_configs3.json",))
     t_ms = elapsed / args.steps * 1e3
     comp = 8 * n + 8 * C * n // D
     actual = sum(v["algorithmic_bytes"] for v in ks.values())
@@ -371,6 +391,7 @@ def run_streambank(P, rank, world, device, barrier, args, dist):
         sp.append(sb.last_ms(2))
     n = S * F * N
     ks, roof = kernel_lines([("k_fastfir_t128", float(np.mean(bp[1:])), 16 * n), (sb.spectrum_kernels(), float(np.mean(sp[1:])), 12 * n)])
+    attach_measured_traffic(ks, roof, ("r03_traffic_configs4.json",))
     t_ms = elapsed / args.steps * 1e3
     out = {"workload": "configs[4] shard: %d streams/GPU x %d frames of 65536, FastFIR 2048/1025 + 65536-point spectrum" % (S, F),
            "streams_per_gpu": S, "streams_total": S * world, "samples_per_step_per_gpu": n, "ms_per_step": round(t_ms, 4), "settle_steps": settled,

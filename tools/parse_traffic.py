@@ -42,16 +42,35 @@ def main(fetch_dir, write_dir, out):
         f, w = first(fe, key), first(wr, key)
         cal[lanes] = {"fetch_KiB": f, "write_KiB": w, "read_scale": gib / (f * 1024.0), "write_scale": gib / (w * 1024.0)}
     res = {"calibration": cal, "kernels": {}}
-    # loads: k_spectrum and k_wfm_fir/k_cascade use 8-byte lanes, k_mix_dec1 / k_mix_hb11_lean / k_mix_hb11_bank 16-byte lanes; stores: spectrum 16-byte, rest 8-byte
-    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_mix_hb11_lean": (16, 8), "k_mix_hb11_bank": (16, 8), "k_cascade": (8, 8), "k_wfm_fir": (8, 8),
-             "k_mix_dec_fused": (8, 8), "k_fastfir_t128": (8, 8), "k_demod_copy": (8, 8)}
-    for name, (lr, lw) in lanes.items():
-        f, w = first(fe, name), first(wr, name)
-        if f is None:
+    # lane widths of the loads / stores (which copy probe scales the counter); kernels not listed use 8-byte lanes both ways
+    lanes = {"k_spectrum": (8, 16), "k_mix_dec1": (16, 8), "k_mix_hb11_lean": (16, 8), "k_mix_hb11_bank": (16, 8)}
+
+    def short(k):
+        k = k.replace("void ", "").replace("pg::", "")
+        for stop in "<(":
+            if stop in k:
+                k = k[:k.index(stop)]
+        return k.strip()
+
+    names = collections.defaultdict(list)
+    for k in fe:
+        if not short(k).startswith("k_probe"):
+            names[short(k)].append(k)
+    # (template instances of one kernel are pooled under its bare name, and every launch of the run counts: the workload scripts
+    # run one route per kernel name; "k_spectrum" keeps its historical key for whichever 8192-bin instance ran)
+    for name, full in sorted(names.items()):
+        fv = [v for k in full for v in fe[k]]
+        wv = [v for k in full for v in wr.get(k, [])]
+        if not fv or not wv:
             continue
+        lr, lw = next((v for key, v in lanes.items() if name.startswith(key)), (8, 8))
+        f, w = sum(fv) / len(fv), sum(wv) / len(wv)
         rb = f * 1024.0 * cal[lr]["read_scale"]
         wb = w * 1024.0 * cal[lw]["write_scale"]
-        res["kernels"][name] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "read_bytes": rb, "write_bytes": wb, "hbm_bytes": rb + wb}
+        res["kernels"][name] = {"launches": len(fv), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "read_bytes": rb, "write_bytes": wb, "hbm_bytes": rb + wb}
+    for name in list(res["kernels"]):
+        if name.startswith("k_spectrum_") and "k_spectrum" not in res["kernels"]:
+            res["kernels"]["k_spectrum"] = dict(res["kernels"][name], instance=name)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

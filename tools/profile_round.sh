@@ -13,17 +13,20 @@ timeout -k 10 600 python3 bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err
 # per-kernel durations of the bench command
 rm -rf $o/${tag}_trace; rocprofv3 --kernel-trace --stats -d $o/${tag}_trace -- python3 bench.py --steps 20 --no-cpu-baseline > $o/${tag}_trace.log 2>&1
 python3 tools/kernel_stats.py $o/${tag}_trace $o/${tag}_kernel_stats.csv > /dev/null
-# HBM traffic of the headline workload and of the configs[2] bank (separate FETCH_SIZE / WRITE_SIZE passes)
-for w in head bank; do
-  if [ $w = head ]; then script="tools/pmc_workload.py"; else script="tools/pmc_bank.py 2"; export PMC_CALIBRATE=1; fi
+# HBM traffic of the headline workload, the configs[2] bank, the configs[3] shard and the configs[4] shard (separate FETCH_SIZE / WRITE_SIZE passes)
+export PMC_CALIBRATE=1
+for w in head configs2 configs3 configs4; do
+  case $w in head) script="tools/pmc_workload.py";; configs2) script="tools/pmc_bank.py 2";; configs3) script="tools/pmc_bank.py 3";; configs4) script="tools/pmc_streambank.py";; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $o/${tag}_pmc_${w}_$c; rocprofv3 --pmc $c --kernel-trace -d $o/${tag}_pmc_${w}_$c -- python3 $script > $o/${tag}_pmc_${w}_$c.log 2>&1
   done
   python3 tools/parse_traffic.py $o/${tag}_pmc_${w}_FETCH_SIZE $o/${tag}_pmc_${w}_WRITE_SIZE $o/${tag}_traffic_${w}.json > /dev/null
 done
 unset PMC_CALIBRATE
-# SQ counters of the two kernels the round worked on
-bash tools/run_sq_counters.sh ${tag}_spectrum k_spectrum_t128 tools/pmc_workload.py > /dev/null
-bash tools/run_sq_counters.sh ${tag}_fused_dec k_mix_dec_fused tools/pmc_bank.py 2 > /dev/null
-rm -rf $o/${tag}_trace $o/${tag}_pmc_* $o/${tag}_spectrum $o/${tag}_fused_dec
+# SQ counters of the kernels the round worked on
+bash tools/run_sq_counters.sh ${tag}_fused_dec k_mix_dec_mfma tools/pmc_bank.py 2 > /dev/null
+bash tools/run_sq_counters.sh ${tag}_cic_dec k_mix_dec_mfma tools/pmc_bank.py 3 > /dev/null
+bash tools/run_sq_counters.sh ${tag}_big256_rows k_big256_rows tools/pmc_streambank.py > /dev/null
+bash tools/run_sq_counters.sh ${tag}_big256_cols k_big256_cols tools/pmc_streambank.py > /dev/null
+rm -rf $o/${tag}_trace $o/${tag}_pmc_* $o/${tag}_fused_dec $o/${tag}_cic_dec $o/${tag}_big256_rows $o/${tag}_big256_cols
 ls -la $o | grep ${tag}_
