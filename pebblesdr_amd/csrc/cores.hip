@@ -685,6 +685,7 @@ void DecimCore::release()
     buf0.release();
     buf1.release();
     fin.release();
+    fin2.release();
     if (d_wide_taps) (void)hipFree(d_wide_taps);
     d_wide_taps = nullptr;
     for (int i = 0; i < 2; i++) {
@@ -808,6 +809,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (n <= 0 || n % (long long)chain.total != 0)
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
+    if (fin2.base) std::swap(fin, fin2);  // alternate calls write alternate output buffers (tail_job_out carries the look-back across)
     const HistBuf *src = &buf0;
     last_fused = false;
     const bool had_bank_state = bank_state_valid;
@@ -934,18 +936,38 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     }
     return 0;
 }
-void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
+void DecimCore::tail_jobs_dec(std::vector<TailJob> &jobs) const
 {
     if (last_fused) {
         // the call's last first-stage outputs (staged by the kernel) become the stage-0 head-room, as if the buffer had been written
         const HistBuf &y0b = fused_front ? buf1 : buf0;
         jobs.push_back(TailJob{d_y0stage, (long long)fused_hy, (long long)fused_hy, fused_hy, 0, y0b.base + (y0b.hist - fused_hy), y0b.pitch});
-        if (fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
         return;
     }
-    if (!fused_front && buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
+    if (!fused_front && buf0.hist > 0 && casc.nst > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
     if (wide && buf1.hist > 0) jobs.push_back(TailJob{buf1.data(), buf1.pitch, len1, buf1.hist, 0, nullptr, 0});
-    if (casc.nst > 0 && fin.hist > 0) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
+}
+void DecimCore::tail_job_out(std::vector<TailJob> &jobs) const
+{
+    if (casc.nst == 0) {  // a single stage: its buffer is the output
+        if (!fused_front && buf0.hist > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});
+        return;
+    }
+    if (fin.hist <= 0) return;
+    // (two output buffers: the next call writes the other one, whose head-room row starts at its base)
+    if (fin2.base) jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, fin2.base, fin2.pitch});
+    else jobs.push_back(TailJob{fin.data(), fin.pitch, len_out, fin.hist, 0, nullptr, 0});
+}
+void DecimCore::tail_jobs(std::vector<TailJob> &jobs) const
+{
+    tail_jobs_dec(jobs);
+    tail_job_out(jobs);
+}
+int DecimCore::enable_double_out()
+{
+    if (casc.nst == 0 || !fin.base) return fail(PEBBLEGPU_E_UNSUPPORTED, "a single-stage chain has no separate output buffer to double");
+    if (fin2.base) return 0;
+    return fin2.alloc(fin.chans, fin.hist, fin.cap);
 }
 
 int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa)
@@ -960,6 +982,13 @@ int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdva
         if (jobs[i].hist > maxh) maxh = jobs[i].hist;
     }
     if (maxh > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "history of %d samples too deep for the tail refresh", maxh);
+    return 0;
+}
+int run_nap(hipStream_t s, unsigned ticks_100mhz)
+{
+    if (ticks_100mhz == 0) return 0;
+    launch(k_nap, dim3(1), dim3(64), s, ticks_100mhz);
+    PG_HIP(hipGetLastError());
     return 0;
 }
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa)

@@ -82,6 +82,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY, WARM = G::warm;
     constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
     __shared__ float2 tiles[4][2][16 * 65];
+    __builtin_amdgcn_s_setprio(3);  // in front of the previous call's band-pass waves beside it (two-stage calls): this kernel is the call's length
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pairs = (P.n_chunks + 1) >> 1;

@@ -817,6 +817,15 @@ static __global__ __launch_bounds__(256) void k_gate_zero(float2 *__restrict__ a
 // All history tails of a call in one launch: buf[c][-hist + j] = buf[c][n - hist + j], j < hist, for every buffer.
 // n may be shorter than hist (then part of the old history is kept, shifted), so a workgroup first reads every value
 // it will write.  grid (1, C, jobs), hist <= 256*32.
+// One wave that sleeps for `ticks` of the 100 MHz wall clock (bounded: at most 4096 naps whatever the clock reads).  Queued in front of
+// the second stage of a two-stage call so that the NEXT call's decimator, which becomes ready at the same moment on the other stream, has
+// its workgroups placed first (Receiver::process).
+static __global__ __launch_bounds__(64) void k_nap(unsigned ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < 4096 && wall_clock64() - t0 < (unsigned long long)ticks; i++) __builtin_amdgcn_s_sleep(8);
+}
+
 static __global__ __launch_bounds__(256) void k_save_tails(TailJobs jobs)
 {
     save_tails_block(jobs, (int)blockIdx.z, (int)blockIdx.y, (int)threadIdx.x);

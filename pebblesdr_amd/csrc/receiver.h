@@ -38,6 +38,7 @@ int make_twiddles(int n, float2 **d_tw);
 int make_twiddles_t128(float2 **d_tw);
 int make_twiddles_t128q(float2 **d_tw);  // four tables, the pruned transform's per-work-item factor folded in (k_spectrum_t128)
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa = nullptr);
+int run_nap(hipStream_t s, unsigned ticks_100mhz);  // one sleeping wave (k_nap)
 int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa);  // 0, or a failure code (too many / too deep)
 int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, const float *final_scale = nullptr);
 int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
@@ -156,6 +157,14 @@ struct DecimCore {
     // the first kernels this call would run read raw device-format samples themselves (k_mix_hb11_lean + its edge launch)
     bool raw_ready(const OscBank &osc) const { return bank_front && C == 1 && want_lds_free && !osc.any_transient() && !(fused_all || bank_mfma); }
     void tail_jobs(std::vector<TailJob> &jobs) const;  // after run(): what must be refreshed before the next call
+    // Two output buffers, written by alternate calls, so that whatever reads a call's output (the band-pass) may run on another stream
+    // beside the NEXT call's decimator: the consumer's look-back (the head-room) is carried from the buffer just written into the other
+    // one's head-room.  tail_jobs() = tail_jobs_dec() (the decimator's own histories: its stream) + tail_job_out() (the consumer's stream)
+    HistBuf fin2;
+    int enable_double_out();                 // after init(); fails for a single-stage chain (its output is the first stage's buffer)
+    bool double_out() const { return fin2.base != nullptr; }
+    void tail_jobs_dec(std::vector<TailJob> &jobs) const;
+    void tail_job_out(std::vector<TailJob> &jobs) const;
     const HistBuf &out() const { return casc.nst > 0 ? fin : buf0; }
     long long out_len() const { return len_out; }
 };
@@ -447,6 +456,9 @@ private:
     hipEvent_t spec_end_ = nullptr;   // pipelined calls: the last display transform queued on the main stream (for the chain's stream to wait on at a join)
     bool pipeline_ = false;           // successive side-by-side calls overlap (PEBBLEGPU_PIPELINE=1 when the receiver is created)
     bool touched_ = true;             // a setter ran since the last call
+    bool bank_pipe_ok_ = false;       // no display transform: the call's two stages (decimator | band-pass .. resampler) on the two streams, stage 2 beside the next call's stage 1
+    hipEvent_t f_end_[2] = {nullptr, nullptr};  // where stage 2 of the last and of the last-but-one such call ended
+    hipEvent_t d_end_prev_ = nullptr;           // where stage 1 of the last call ended, if that was a two-stage call (the next one starts there)
     bool fuse_dec_ = false;           // the one-channel decimator inside the display transform's kernel (PEBBLEGPU_FUSE_DEC=1 at creation)
     hipEvent_t chain_end_ = nullptr;  // set when a two-stream call failed half-way: what was queued on the chain stream, for the main stream to wait on
     std::vector<ChanCtl> ctl_;

@@ -55,6 +55,21 @@ int Receiver::create(const pebblegpu_config *cfg)
     if (int rc = dec_.init(C, chain, max_n, wfm ? 0 : (int)ff_taps - 1, gain)) return rc;
     if (int rc = audio.alloc((int)C, 0, nd_max)) return rc;
     if (!wfm) {
+        // Two-stage calls (the band-pass and everything behind it on the chain's stream, beside the NEXT call's decimator): needs the
+        // decimator's output twice (PEBBLEGPU_BANK_PIPELINE=0 when the receiver is created keeps every call on one stream)
+        { const char *e = getenv("PEBBLEGPU_BANK_PIPELINE"); bank_pipe_ok_ = !(e && e[0] == '0') && chain.stages.size() > 1 && !bins; }
+        if (bank_pipe_ok_) {
+            if (int rc = dec_.enable_double_out()) return rc;
+            // The second stage runs in what the decimator leaves idle: its stream has the lower priority, so that when a call's decimator
+            // and the previous call's band-pass become ready together (both wait for the same launch) the decimator's workgroups are placed
+            // first -- the other way round the band-pass filled the CUs and the decimator, one 230-register wave per SIMD, took 112 us
+            // instead of 65 waiting for room
+            int lo = 0, hi = 0;
+            PG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            (void)hipStreamDestroy(chain_stream_);
+            chain_stream_ = nullptr;
+            PG_HIP(hipStreamCreateWithPriority(&chain_stream_, hipStreamNonBlocking, lo));
+        }
         if (int rc = ff_.init(C, ff_n, ff_taps)) return rc;
         if (int rc = am_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_AM(m_inputSampleRate), demod.cpp:62
         // Demod_SAM / Demod_NFM objects also exist in every Receiver (demod.cpp:63-64); their buffers are allocated on first use
@@ -348,7 +363,14 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // call's transform instead of on an idle GPU.  Results are complete after sync() (the contract of include/pebblegpu.h).
     // Anything else -- a control change to apply, a call of another shape -- first orders the two queues behind each other.
     const bool was_touched = touched_;
-    const bool plain = side && pipeline_ && !touched_;
+    // Two-stage calls of a receiver without a display transform: mixer + decimator (and the refresh of their histories) on the main
+    // stream, band-pass, noise filter, AGC, demodulators and resampler on the chain's stream behind an event -- the decimator of the next
+    // call does not wait for them (it writes the other output buffer; it does wait for the band-pass of the call before the last, which
+    // read that buffer).  The decimator of a bank leaves the vector units idle two thirds of the time (one wave per SIMD, bound by
+    // its own instruction stream): the band-pass of the previous call fits beside it.  Results are complete after sync().
+    const bool bank_pipe = bank_pipe_ok_ && with_chain && !with_spectrum && !profile_detail && squelch_db_ <= -120.0 && !bank_gate_ && !zoom_bins &&
+                           !cond_.any && !cond_.dirty && dec_.double_out();
+    const bool plain = (side && pipeline_ && !touched_) || (bank_pipe && !touched_);
     auto join = [&]() -> int {
         if (chain_end_) PG_HIP(hipStreamWaitEvent(stream_, chain_end_, 0));
         if (spec_end_) PG_HIP(hipStreamWaitEvent(chain_stream_, spec_end_, 0));
@@ -368,7 +390,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         const bool fused = side && S == 1 && spec_.raw_ready() && dec_.raw_ready(osc_);
         staged = !fused;
         if (!fused) {
-            if (plain) { if (int rc = join()) return rc; }  // the staging buffer is shared by successive calls
+            if (plain && !bank_pipe) { if (int rc = join()) return rc; }  // the staging buffer is shared by successive calls (two-stage calls: only their first stage touches it)
             if (!d_raw_stage_) PG_HIP(hipMalloc((void **)&d_raw_stage_, sizeof(float2) * (size_t)S * max_sf * superframe));
             // streams are stream-major in both layouts, so one pass over S * n pairs converts them all
             if (int rc = run_normalize_iq(raw->fmt, raw->order, 1.0, raw->base, (long long)(S * n), d_raw_stage_, stream_, false, &raw->scale)) return rc;
@@ -386,10 +408,11 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // records no end event: it ends where the next call's start event is recorded (same queue, nothing in between), or where
     // sync() / a timing query closes it (close_timing).
     hipEvent_t start = ev[0];
-    PG_HIP(hipEventRecord(ev[0], stream_));
+    if (bank_pipe && plain && d_end_prev_) start = d_end_prev_;  // (a two-stage call begins where the previous one's first stage ended: one queue packet less)
+    else PG_HIP(hipEventRecord(ev[0], stream_));
     tm.start_ev[slot] = start;
     if (tm.open_slot >= 0) {
-        tm.end_ev[tm.open_slot] = ev[0];
+        tm.end_ev[tm.open_slot] = start;
         tm.open_slot = -1;
     }
     tm.end_ev[slot] = ev[6];
@@ -397,6 +420,8 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (side) {
         PG_HIP(hipStreamWaitEvent(chain_stream_, start, 0));  // fork: the input is ready where the call starts
     }
+    // the output buffer this call writes was read two calls ago (a wait is a queue packet: none when the host can see that it is over)
+    if (bank_pipe && f_end_[1] && hipEventQuery(f_end_[1]) != hipSuccess) PG_HIP(hipStreamWaitEvent(stream_, f_end_[1], 0));
     // From here on a failing step leaves kernels queued (on the chain stream too) and histories half advanced: whatever the
     // exit, join the two streams so later work is ordered behind what was queued, and refuse further calls on the handle.
     struct Guard {
@@ -407,7 +432,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             r->failed_ = true;
             if (side && hipEventRecord(ev[6], cs) == hipSuccess) r->chain_end_ = ev[6];
         }
-    } guard{this, ev, cs, side, true};
+    } guard{this, ev, bank_pipe ? chain_stream_ : cs, side || bank_pipe, true};
     // One channel through hb11 x 8, hb15, hb23, hb47 beside the 8192-bin transform: the transform's workgroups can compute the decimator
     // from the frames they hold (k_spectrum_t128<.., DEC>): the stream crosses HBM once, nothing is written at the intermediate rates.
     // Opt-in (PEBBLEGPU_FUSE_DEC=1 when the receiver is created): measured slower -- the stages sit in the kernel's barrier intervals,
@@ -444,6 +469,21 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));  // everything behind the decimator reads what the transform's kernel wrote
     } else if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw)) return rc;
     if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
+    if (bank_pipe) {
+        // the decimator's own histories and the oscillators' phases stay on its stream; the rest of the call moves over
+        std::vector<TailJob> jobs;
+        dec_.tail_jobs_dec(jobs);
+        OscAdvance oa;
+        if (int rc = osc_.advance_job(stream_, n, &oa)) return rc;
+        if (int rc = run_save_tails(stream_, jobs, C, &oa)) return rc;
+        PG_HIP(hipEventRecord(ev[1], stream_));
+        cs = chain_stream_;
+        PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+        // (the next call's decimator becomes ready with the same event: a short nap lets its one-wave-per-SIMD workgroups be placed before
+        // the band-pass fills the CUs -- placed behind them it ran 112 us instead of 65)
+        static const unsigned nap = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_NAP_US"); return (unsigned)(100.0 * (e ? atof(e) : 8.0)); }();
+        if (int rc = run_nap(cs, nap)) return rc;
+    }
     const long long nd = dec_.out_len();
     if (zoom_bins) {  // SignalSpectrum::zoomed(m_sampleBuf, numStepSamples), receiver.cpp:884 / :942 (the update timer forced open)
         if (int rc = zoom_.run(cs, dec_.out().data(), dec_.out().pitch, nd / nf, d_zoom)) return rc;
@@ -522,7 +562,11 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         }
     }
     if (profile_detail) PG_HIP(hipEventRecord(ev[5], cs));
-    if (!tails_carried) {  // one launch refreshes every history head-room for the next call
+    if (bank_pipe) {
+        std::vector<TailJob> jobs;
+        dec_.tail_job_out(jobs);
+        if (int rc = run_save_tails(cs, jobs, C, nullptr)) return rc;
+    } else if (!tails_carried) {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
@@ -530,7 +574,15 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (int rc = osc_.advance_job(cs, n, &oa)) return rc;
         if (int rc = run_save_tails(cs, jobs, C, &oa)) return rc;
     }
-    if (side && pipeline_) {
+    if (!bank_pipe) d_end_prev_ = nullptr;
+    if (bank_pipe) {
+        PG_HIP(hipEventRecord(ev[6], cs));
+        chain_end_ = ev[6];   // for whoever needs both stages over: sync(), a call after a setter, a call of another shape
+        spec_end_ = ev[1];
+        f_end_[1] = f_end_[0];
+        f_end_[0] = ev[6];
+        d_end_prev_ = ev[1];
+    } else if (side && pipeline_) {
         // the call's two pipelines end separately: whoever needs both waits for both (sync(), the next call that is not plain)
         PG_HIP(hipEventRecord(ev[6], cs));
         chain_end_ = ev[6];

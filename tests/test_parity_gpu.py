@@ -1958,6 +1958,64 @@ def test_pipelined_calls_run_back_to_back_and_match_joined_calls(gpu_lib, monkey
             bf.free()
 
 
+@pytest.mark.parametrize("fs,C,modes", [(2048000, 64, "usb"), (2048000, 20, "am_usb_fm"), (100000000, 64, "am_usb")])
+def test_two_stage_calls_back_to_back_equal_single_stream_calls(gpu_lib, monkeypatch, fs, C, modes):
+    """A receiver without a display transform runs every call in two stages on two streams (mixer + decimator | band-pass, AGC,
+    demodulators), the second stage beside the NEXT call's decimator, which writes the other of two output buffers; the band-pass's
+    look-back is carried from one buffer into the other's head-room.  Calls queued without a host synchronisation in between
+    -- one, two, ... seven in a row, a retune and a mode change before the fifth (a setter orders the two streams behind each other
+    first) -- must leave bit for bit the audio a receiver created with PEBBLEGPU_BANK_PIPELINE=0 (every call on one stream, one
+    output buffer) leaves after the same calls.  Banks on both first-stage forms, AM / USB / NFM channels mixed."""
+    import pebblesdr_amd as P
+    monkeypatch.setenv("PEBBLEGPU_BANK_PIPELINE", "0")
+    b = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    monkeypatch.delenv("PEBBLEGPU_BANK_PIPELINE")
+    a = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    kinds = {"usb": [P.DM_USB], "am_usb": [P.DM_AM, P.DM_USB], "am_usb_fm": [P.DM_AM, P.DM_USB, P.DM_FMN]}[modes]
+    fcs = [(-0.4 + 0.8 * (c + 0.5) / C) * fs for c in range(C)]
+    for rx in (a, b):
+        for c in range(C):
+            m = kinds[c % len(kinds)]
+            rx.set_mode(c, m); rx.set_mixer(c, fcs[c])
+            rx.set_bandpass(c, 300, 3000) if m == P.DM_USB else rx.set_bandpass(c, -4000, 4000)
+    K = 7
+    sf = a.superframe
+    lens = [2 * sf, sf, 2 * sf, 2 * sf, sf, 2 * sf, 2 * sf] if fs < 50_000_000 else [sf] * K  # (a super-frame at 100 Msps is 4 M samples)
+    x = (tones(fs, sum(lens), [(0.05, fc + 1000.0 + 40.0 * i) for i, fc in enumerate(fcs[:: max(1, C // 8)])]) + lcg_noise(sum(lens), 5, 1e-2)).astype(np.complex64)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    bufs = [P.DeviceBuffer.from_array(P.binding.to_f32_iq(x[offs[k]:offs[k + 1]]), 0) for k in range(K)]
+
+    def retune(rx):
+        rx.set_mixer(1, fcs[1] + 700.0)
+        rx.set_mode(2, P.DM_LSB)
+        rx.set_bandpass(2, -3000, -300)
+    try:
+        want = []
+        for k in range(K):
+            if k == 4:
+                retune(b)
+            b.process_device(bufs[k].ptr, lens[k])
+            b.synchronize()
+            want.append(b.audio().copy())
+        assert np.abs(want[-1]).max() > 1e-3
+        k = 0
+        for run in (1, 2, 1, 3):  # calls 0 | 1 2 | 3 | 4 5 6, each group queued back to back
+            if k == 4:
+                retune(a)
+            for _ in range(run):
+                a.process_device(bufs[k].ptr, lens[k])
+                k += 1
+            a.synchronize()
+            got = a.audio()
+            assert got.shape == want[k - 1].shape
+            assert np.array_equal(got, want[k - 1]), "after call %d" % (k - 1)
+        if C >= 16:
+            assert a.kernel_name(2) == "k_mix_dec_mfma"
+    finally:
+        for bf in bufs:
+            bf.free()
+
+
 def test_decimator_inside_the_display_transform_switches_routes_with_a_retune(gpu_lib, monkeypatch):
     """PEBBLEGPU_FUSE_DEC=1: calls inside an oscillator transient (the first one, the one after a retune) take the stand-alone
     kernels, the others run the decimator inside k_spectrum_t128 -- each route leaves what the other needs in front of the next call
