@@ -210,8 +210,10 @@ int OscBank::upload(hipStream_t s)
         PG_HIP(hipMemcpyAsync(d_osc + ch, &o, sizeof(ChanOsc), hipMemcpyHostToDevice, s));
         PG_HIP(hipStreamSynchronize(s));
         c.dirty = false;
+        dyn_epoch++;
     }
     if (device_advance && dev_dyn_valid && C > (uint32_t)kOscInline) return 0;  // the previous call's tail launch advanced them on the device
+    dyn_epoch++;
     // every call: phase and amplitude-transient position, 16 bytes per channel, from pinned ping-pong staging
     const int cur = h_idx;
     h_idx ^= 1;
@@ -383,7 +385,7 @@ static int launch_bank(void *kern, unsigned n_wg, hipStream_t s, const float2 *d
 }
 
 // the call's decimator as one launch of k_mix_dec_mfma (the caller has checked the sizes)
-int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, const OscBank &osc, bool had_state)
+int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, const OscBank &osc, bool had_state, const OscAdvance *oa)
 {
     const bool cic = fused_front;
     const HistBuf &y0b = cic ? buf1 : buf0;
@@ -394,6 +396,19 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
     if (!bv) return fail(PEBBLEGPU_E_UNSUPPORTED, "no k_mix_dec_mfma instance for this chain");
     const long long g32 = cdiv(C, 32);
     const int warm = (bv->hy - 8) / 8;
+    // The first-stage outputs in front of the call's start (block 0 needs seven of them even with the running sums handed over; the whole
+    // look-back without): from the stage-0 head-room when the previous call took another route, else straight from what the previous
+    // launch staged (two staging buffers, written alternately: this launch's history waves write the other one)
+    const float2 *y0_hist = y0_pending ? (const float2 *)(d_y0stage2[y0_cur] + fused_hy) : (const float2 *)y0b.data();
+    const long long y0_hist_pitch = y0_pending ? (long long)fused_hy : y0b.pitch;
+    // the oscillators' advance rides on the launch when the caller handed it over (banks whose oscillators live on the device)
+    static const int adv_mode = [] { const char *e = getenv("PEBBLEGPU_BANK_OSC_ADV"); return e ? atoi(e) : 1; }();  // 0: leave the oscillators to the tail launch (A/B)
+    const bool adv = adv_mode != 0 && oa != nullptr && oa->osc != nullptr && oa->osc_count == C;
+    if (adv && !d_dyn[0]) {
+        for (int i = 0; i < 2; i++) PG_HIP(hipMalloc((void **)&d_dyn[i], sizeof(OscDyn) * C));
+    }
+    if (osc.dyn_epoch != dyn_epoch_seen) dyn_valid = false;
+    dyn_epoch_seen = osc.dyn_epoch;
     // One wave per SIMD pays the fewest warm-up blocks; two overlap what a lone wave leaves idle (measured on hb11 x 4, 15/19/31: 1200
     // clocks per block alone, 2075 for each of two) -- worth it once a chunk is long against its warm-up: from 128 outputs per chunk on
     int waves = bank_waves;
@@ -430,7 +445,7 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
     auto common = [&](auto &bp) {
         bp.n_out = len_out;
         bp.out_pitch = fin.pitch;
-        bp.y0_pitch = y0b.pitch;
+        bp.y0_pitch = y0_hist_pitch;
         bp.n_in = n;
         bp.S = Sfs;
         bp.L = (int)L;
@@ -446,6 +461,11 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
         bp.state_in = had_state ? d_bank_state[bank_state_parity] : nullptr;
         bp.state_out = d_bank_state[bank_state_parity ^ 1];
         bp.clk = want_clk ? d_clk : nullptr;
+        bp.dyn_in = adv && dyn_valid ? d_dyn[dyn_parity] : nullptr;
+        bp.dyn_out = adv ? d_dyn[dyn_parity ^ 1] : nullptr;
+        bp.osc_rw = adv ? oa->osc : nullptr;
+        bp.adv = adv ? oa->adv : nullptr;
+        bp.adv_n = adv ? oa->adv_n : 0;
     };
     const float2 *xh = d_xhist[hist_parity];
     float2 *xh_out = d_xhist[hist_parity ^ 1], *mixed = d_hist_mixed[hist_parity ^ 1];
@@ -470,7 +490,7 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
             kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 2> : dbg == 3 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 3>
                  : dbg == 4 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 4> : dbg == 8 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 16>
                  : dbg == 31 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 31> : dbg == 100 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 0, 1> : kern;
-        if (int rc = launch_bank<4>(kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, (const float2 *)y0b.data(), d_y0stage, mixed, bp)) return rc;
+        if (int rc = launch_bank<4>(kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp)) return rc;
     } else {
         // CIC3 at stride S0 in the reference's merged form (decimator.cpp:719-737: output k = .125 (od_k + ev_{k-1} + 3 (od_{k-1} + ev_k)) of the
         // sample pairs (ev, od)_P = x[S0 P], x[S0 P + 1]) under the hb11 at stride 16: relative to sample S j, pair q = -11 .. 0 carries
@@ -489,7 +509,7 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
             bp.oa[2 * i + 1] = S0 * (-11 - q);  bp.ob[2 * i + 1] = S0 * q + 1;  bp.g[2 * i + 1] = (h(q + 10) + 3.f * h(q + 11)) * 0.125f;
         }
         for (int p = 0; p < 12; p++) bp.e[p] = 0.5f * (float)(bp.oa[p] - bp.ob[p]);
-        if (int rc = launch_bank<12>(bv->kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, (const float2 *)y0b.data(), d_y0stage, mixed, bp)) return rc;
+        if (int rc = launch_bank<12>(bv->kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp)) return rc;
     }
     if (want_clk) {
         std::vector<unsigned long long> h((size_t)n_wg * 16);
@@ -525,7 +545,26 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
     front_name = "k_mix_dec_mfma";
     rest_name = "";
     last_fused = true;
+    last_mfma = true;
+    y0_cur ^= 1;
+    y0_pending = true;
+    // (with dyn_in the launch advanced the device blocks too; without, the caller's tail launch does and the next call finds dyn_out current)
+    osc_advanced = adv && dyn_valid;
+    if (adv) dyn_parity ^= 1;
+    dyn_valid = adv;
     return 0;
+}
+
+// The first-stage history a k_mix_dec_mfma launch staged (d_y0stage) into the stage-0 head-room, where the other routes and a launch
+// without the halfbands' running sums look for it.  Not needed between two such launches: queued only when a call wants it.
+int DecimCore::flush_y0(hipStream_t s)
+{
+    if (!y0_pending) return 0;
+    const HistBuf &y0b = fused_front ? buf1 : buf0;
+    std::vector<TailJob> jobs;
+    jobs.push_back(TailJob{d_y0stage2[y0_cur], (long long)fused_hy, (long long)fused_hy, fused_hy, 0, y0b.base + (y0b.hist - fused_hy), y0b.pitch});
+    y0_pending = false;
+    return run_save_tails(s, jobs, C, nullptr);
 }
 
 int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain)
@@ -630,7 +669,11 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
                 PG_HIP(hipMalloc((void **)&d_xhist[i], sizeof(float2) * xh_depth));
                 PG_HIP(hipMemset(d_xhist[i], 0, sizeof(float2) * xh_depth));
             }
-            PG_HIP(hipMalloc((void **)&d_y0stage, sizeof(float2) * (size_t)fused_hy * C));
+            for (int i = 0; i < 2; i++) {  // (64 entries of slack: the kernel requests a block ahead of what it uses)
+                PG_HIP(hipMalloc((void **)&d_y0stage2[i], sizeof(float2) * ((size_t)fused_hy * C + 64)));
+                PG_HIP(hipMemset(d_y0stage2[i], 0, sizeof(float2) * ((size_t)fused_hy * C + 64)));
+            }
+            d_y0stage = d_y0stage2[0];
             const char *ew = getenv("PEBBLEGPU_BANK_WAVES");
             bank_waves = ew ? atoi(ew) : 0;  // 0: chosen per call
             if (bank_waves < 0 || bank_waves > 4) bank_waves = 0;
@@ -676,11 +719,18 @@ void DecimCore::release()
         if (d_xhist[i]) (void)hipFree(d_xhist[i]);
         d_xhist[i] = nullptr;
     }
-    if (d_y0stage) (void)hipFree(d_y0stage);
+    for (int i = 0; i < 2; i++) {
+        if (d_y0stage2[i]) (void)hipFree(d_y0stage2[i]);
+        d_y0stage2[i] = nullptr;
+    }
     d_y0stage = nullptr;
     for (int i = 0; i < 2; i++) {
         if (d_bank_state[i]) (void)hipFree(d_bank_state[i]);
         d_bank_state[i] = nullptr;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (d_dyn[i]) (void)hipFree(d_dyn[i]);
+        d_dyn[i] = nullptr;
     }
     buf0.release();
     buf1.release();
@@ -803,7 +853,7 @@ int DecimCore::run_beside_spectrum(hipStream_t s, const float2 *d_in, long long 
     return 0;
 }
 int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
-                   hipEvent_t after_first, const RawSrc *raw)
+                   hipEvent_t after_first, const RawSrc *raw, const OscAdvance *oa)
 {
     if (raw && !raw_ready(osc)) return fail(PEBBLEGPU_E_INVALID, "raw-format input reached a decimator path that has no converting loads");
     if (n <= 0 || n % (long long)chain.total != 0)
@@ -812,8 +862,12 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (fin2.base) std::swap(fin, fin2);  // alternate calls write alternate output buffers (tail_job_out carries the look-back across)
     const HistBuf *src = &buf0;
     last_fused = false;
+    last_mfma = false;
+    osc_advanced = false;
     const bool had_bank_state = bank_state_valid;
     bank_state_valid = false;  // (set again below when this call takes the matrix-pipe route)
+    const bool had_dyn = dyn_valid;
+    dyn_valid = false;
     if ((fused_all || bank_mfma) && shared_input && !osc.any_transient()) {
         const HistBuf &y0b = fused_front ? buf1 : buf0;  // the first-stage (hb11) outputs' buffer of the other route: its head-room is the history
         if (n / ((long long)first.stride * (fused_front ? wide_stride : 1)) > y0b.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
@@ -827,10 +881,12 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         }
         if (bank_mfma && (unsigned long long)n * 8 < 0xFFF00000ull && (unsigned long long)C * (unsigned long long)fin.pitch * 8 < 0xFFF00000ull &&
             len_out >= 64 && (reinterpret_cast<uintptr_t>(d_in) & 7) == 0) {  // (its sample fetches and result stores carry 32-bit byte offsets)
-            if (int rc = run_bank_mfma(s, d_in, n, osc, had_bank_state)) return rc;
+            dyn_valid = had_dyn;
+            if (int rc = run_bank_mfma(s, d_in, n, osc, had_bank_state, oa)) return rc;
             if (after_first) PG_HIP(hipEventRecord(after_first, s));
             return 0;
         }
+      if (int rc = flush_y0(s)) return rc;
       if (fused_all) {
         long long L = fused_L > 0 ? fused_L : ((len_out * groups / 704 + 15) & ~15LL);  // ~700 four-wave workgroups (measured best on 256 CUs: 96 for configs[2]); every chunk pays a 21-block warm-up
         if (L < 32) L = 32;
@@ -850,6 +906,7 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         return 0;
       }
     }
+    if (int rc = flush_y0(s)) return rc;
     if (fused_front) {
         len1 = len0 / wide_stride;
         if (len1 > buf1.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
@@ -940,8 +997,9 @@ void DecimCore::tail_jobs_dec(std::vector<TailJob> &jobs) const
 {
     if (last_fused) {
         // the call's last first-stage outputs (staged by the kernel) become the stage-0 head-room, as if the buffer had been written
+        // (behind k_mix_dec_mfma only when a later call asks for them there: flush_y0)
         const HistBuf &y0b = fused_front ? buf1 : buf0;
-        jobs.push_back(TailJob{d_y0stage, (long long)fused_hy, (long long)fused_hy, fused_hy, 0, y0b.base + (y0b.hist - fused_hy), y0b.pitch});
+        if (!last_mfma) jobs.push_back(TailJob{d_y0stage, (long long)fused_hy, (long long)fused_hy, fused_hy, 0, y0b.base + (y0b.hist - fused_hy), y0b.pitch});
         return;
     }
     if (!fused_front && buf0.hist > 0 && casc.nst > 0) jobs.push_back(TailJob{buf0.data(), buf0.pitch, len0, buf0.hist, 0, nullptr, 0});

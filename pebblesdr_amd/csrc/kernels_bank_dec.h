@@ -64,6 +64,17 @@ struct BankDecParams {
     int hist_split;           // history waves per channel group
     int cic_s0;               // 0: the front is hb11 x S (the two-kernel route keeps ten mixed samples); else the merged CIC3's stride S0 in front of
                               // the hb11 (that route keeps the call's last twelve mixed sample pairs S0 P, S0 P + 1)
+    // The oscillators' per-call fields (OscBank::advance restated on the device) ride on this launch's history waves when the caller
+    // hands them over: dyn_out[c] receives channel c's fields advanced by this call (adv[c] = frac(n inc), adv_n samples).  dyn_in, when
+    // not null, is what the previous such launch wrote for THIS call: every wave then reads phase and mixer switch from it, and the
+    // history waves also advance osc_rw[c] in place (no wave of this launch reads it), so that kernels of the other routes find current
+    // values -- and no tail launch is needed for the oscillators.  With dyn_in == nullptr the waves read osc[c]; the caller's tail launch
+    // advances it in place as before.
+    const OscDyn *dyn_in;
+    OscDyn *dyn_out;
+    ChanOsc *osc_rw;
+    const double *adv;
+    unsigned adv_n, pad_;
     unsigned long long *clk;  // diagnosis (PEBBLEGPU_BANK_CLK): per wave {shader clocks, 100 MHz ticks, blocks} of its block loop; nullptr otherwise
 };
 
@@ -109,6 +120,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     const double inc = oc->inc;
     double phase0 = oc->phase0;
     uint32_t mix_on = oc->mix_on;
+    if (P.dyn_in != nullptr) { phase0 = P.dyn_in[c].phase0; mix_on = P.dyn_in[c].mix_on; }
     if (dyn.use) {
 #pragma unroll
         for (int k = 0; k < kOscInline; k++)
@@ -221,6 +233,20 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
                     const long long j = j0 + k;
                     if (j >= len0 - HY && j < len0) y0_stage[(long long)c * HY + (j - (len0 - HY))] = y0[k];
                 }
+            }
+        }
+        if (P.dyn_out != nullptr && hpart == 0 && lane < 32 && ch_raw < P.n_chan) {
+            // OscBank::advance for this channel (the arithmetic of save_tails_block, tail_refresh.h)
+            double pn = phase0 + P.adv[c];
+            pn -= floor(pn);
+            pn = pn >= 1.0 ? 0.0 : pn;
+            const uint32_t n_old = P.dyn_in != nullptr ? P.dyn_in[c].n0 : oc->n0;
+            uint32_t n_new = n_old + P.adv_n;
+            n_new = n_new > (uint32_t)kAmpTab ? (uint32_t)kAmpTab : n_new;
+            P.dyn_out[c] = OscDyn{pn, n_new, mix_on};
+            if (P.dyn_in != nullptr) {
+                P.osc_rw[c].phase0 = pn;
+                P.osc_rw[c].n0 = n_new;
             }
         }
         if (grp == 0 && hpart == 0) {

@@ -72,6 +72,7 @@ struct OscBank {
     double *d_adv = nullptr;
     uint64_t adv_n = 0;
     bool adv_stale = true;
+    uint64_t dyn_epoch = 0;        // counts host writes of the device blocks' per-call fields (a retune's block, the per-call upload)
     int advance_job(hipStream_t s, uint64_t n, OscAdvance *oa);  // fills *oa (osc == nullptr when the device is not advancing)
     int init(uint32_t channels, double sample_rate);
     void release();
@@ -105,13 +106,15 @@ struct DecimCore {
     bool fused_all = false, last_fused = false;
     struct FusedDecParams *fused_p = nullptr;   // host copy of the kernel's parameter block
     float2 *d_xhist[2] = {nullptr, nullptr};    // [16] raw input tail of the previous call, ping-pong with hist_parity
-    float2 *d_y0stage = nullptr;                // [C][HY] the call's last first-stage outputs, copied into buf0's head-room by the tail refresh
+    float2 *d_y0stage = nullptr;                // [C][HY] the call's last first-stage outputs, copied into buf0's head-room by the tail refresh (k_mix_dec_fused: = d_y0stage2[0])
+    float2 *d_y0stage2[2] = {nullptr, nullptr}; // k_mix_dec_mfma stages them alternately and reads the previous launch's directly (y0_cur: the one written last)
+    int y0_cur = 0;
     int fused_hy = 0, fused_L = 0;
     // the same chain with its first stage on the matrix pipe, one wave per (32 channels, two chunks): k_mix_dec_mfma (kernels_bank_dec.h),
     // the default route of such a bank; PEBBLEGPU_BANK_DEC=0 keeps the four-wave pipeline above
     bool bank_mfma = false;
     int bank_nstate = 0, bank_minw = 2;          // running sums per channel of the chain's instance; waves per SIMD it admits
-    int run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, const OscBank &osc, bool had_state);
+    int run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, const OscBank &osc, bool had_state, const OscAdvance *oa);
     int bank_waves = 0;                          // target waves per SIMD of a launch (PEBBLEGPU_BANK_WAVES, default 1)
     int xh_depth = 16;                           // samples of raw-input tail kept in d_xhist
     float2 *d_bank_state[2] = {nullptr, nullptr};  // [C][38] the halfbands' running sums where the last k_mix_dec_mfma call ended (ping-pong)
@@ -152,8 +155,18 @@ struct DecimCore {
     int init(uint32_t channels, const design::Chain &c, long long max_in, int last_hist, float last_gain);
     void release();
     // n must be a multiple of chain.total; any such n streams exactly (no minimum frame length)
+    // oa (from OscBank::advance_job for this call, or nullptr): when the route's kernel can advance the oscillators itself it does, and
+    // osc_advanced says so (the caller then leaves the advance out of its tail launch)
     int run(hipStream_t s, const float2 *d_in, long long in_pitch, bool shared_input, long long n, const OscBank &osc,
-            hipEvent_t after_first = nullptr, const RawSrc *raw = nullptr);
+            hipEvent_t after_first = nullptr, const RawSrc *raw = nullptr, const OscAdvance *oa = nullptr);
+    bool osc_advanced = false;
+    bool last_mfma = false;                 // the last run() was a k_mix_dec_mfma launch
+    int flush_y0(hipStream_t s);
+    OscDyn *d_dyn[2] = {nullptr, nullptr};  // [C] the oscillators' per-call fields as k_mix_dec_mfma hands them from call to call (ping-pong)
+    int dyn_parity = 0;
+    bool dyn_valid = false;                 // d_dyn[dyn_parity] holds this call's fields (the previous call was such a launch and nothing was uploaded since)
+    uint64_t dyn_epoch_seen = 0;
+    bool y0_pending = false;                // d_y0stage holds first-stage history the stage-0 head-room has not received yet (copied when a call needs it there)
     // the first kernels this call would run read raw device-format samples themselves (k_mix_hb11_lean + its edge launch)
     bool raw_ready(const OscBank &osc) const { return bank_front && C == 1 && want_lds_free && !osc.any_transient() && !(fused_all || bank_mfma); }
     void tail_jobs(std::vector<TailJob> &jobs) const;  // after run(): what must be refreshed before the next call

@@ -464,18 +464,27 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // Mixer::processBlock + Decimator::process, receiver.cpp:867-868 / :910-911
     dec_.want_lds_free = side;
     // an event record costs the stream a ~5 us bubble: per-kernel events only when asked for (set_profiling)
+    OscAdvance oa_pre;
+    memset(&oa_pre, 0, sizeof(oa_pre));
+    bool have_oa = false;
     if (fuse_dec) {
         if (int rc = dec_.run_beside_spectrum(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, raw)) return rc;
         PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));  // everything behind the decimator reads what the transform's kernel wrote
-    } else if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw)) return rc;
+    } else {
+        // (the oscillators' advance is offered to the decimator: the bank kernel carries it in its own launch, DecimCore::osc_advanced)
+        if (!wfm) {
+            if (int rc = osc_.advance_job(cs, n, &oa_pre)) return rc;
+            have_oa = true;
+        }
+        if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw, have_oa ? &oa_pre : nullptr)) return rc;
+        if (have_oa && dec_.osc_advanced) memset(&oa_pre, 0, sizeof(oa_pre));
+    }
     if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
     if (bank_pipe) {
         // the decimator's own histories and the oscillators' phases stay on its stream; the rest of the call moves over
         std::vector<TailJob> jobs;
         dec_.tail_jobs_dec(jobs);
-        OscAdvance oa;
-        if (int rc = osc_.advance_job(stream_, n, &oa)) return rc;
-        if (int rc = run_save_tails(stream_, jobs, C, &oa)) return rc;
+        if (int rc = run_save_tails(stream_, jobs, C, &oa_pre)) return rc;  // (no launch at all behind the bank kernel: nothing left to do)
         PG_HIP(hipEventRecord(ev[1], stream_));
         cs = chain_stream_;
         PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
@@ -570,8 +579,8 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         std::vector<TailJob> jobs;
         dec_.tail_jobs(jobs);
         if (wfm && !gate_closed) wfmc_.tail_jobs(jobs);  // a gated super-frame never reached the demodulator: its history stays
-        OscAdvance oa;
-        if (int rc = osc_.advance_job(cs, n, &oa)) return rc;
+        OscAdvance oa = oa_pre;
+        if (!have_oa) { if (int rc = osc_.advance_job(cs, n, &oa)) return rc; }
         if (int rc = run_save_tails(cs, jobs, C, &oa)) return rc;
     }
     if (!bank_pipe) d_end_prev_ = nullptr;
