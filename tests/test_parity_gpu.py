@@ -823,6 +823,48 @@ def test_process_raw_equals_normalize_then_process(gpu_lib, oracle_mod):
         a.process_raw_device(1, n, 9)  # unknown format
 
 
+def test_process_raw_on_a_shared_stream_bank(gpu_lib):
+    """pebblegpu_receiver_process_raw on a bank of 64 USB channels off one shared stream (RTL2832 uint8 pairs, then HackRF int8 in Q,I
+    order with a gain): the bank's one-kernel decimator takes float2 samples, so normalizeIQ runs as one pass over the SHARED stream on
+    the decimator's stream (2 + 8 bytes per input sample, once for all channels -- the bank reads the stream C / 32 times from L2 after
+    that) -- three calls queued back to back (two-stage calls: each next call's conversion and decimator run beside the previous call's
+    band-pass) must leave bit for bit what a twin leaves that is handed the same samples converted on the host with the reference's
+    constants (deviceinterfacebase.cpp:651, :689)."""
+    import pebblesdr_amd as P
+    fs, C = 2048000, 64
+    rng = np.random.default_rng(21)
+    for fmt, dtype, off, scale, order, gain in ((1, np.uint8, 128.0, 128.0, 0, 1.0), (0, np.int8, 0.0, 128.0, 1, 0.7)):
+        a = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+        b = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+        fcs = [(-0.4 + 0.8 * (c + 0.5) / C) * fs for c in range(C)]
+        for rx in (a, b):
+            for c in range(C):
+                rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+        n = 2 * a.superframe
+        K = 3
+        sig = 40.0 * tones(fs, K * n, [(0.1, fc + 1000.0 + 30.0 * i) for i, fc in enumerate(fcs[::4])])
+        raw = np.empty((K * n, 2), dtype=dtype)
+        raw[:, 0] = np.clip(np.round(sig.real + rng.uniform(-1, 1, K * n) + off), 0 if off else -128, 255 if off else 127).astype(dtype)
+        raw[:, 1] = np.clip(np.round(sig.imag + rng.uniform(-1, 1, K * n) + off), 0 if off else -128, 255 if off else 127).astype(dtype)
+        first, second = (raw[:, 0], raw[:, 1]) if order == 0 else (raw[:, 1], raw[:, 0])
+        g32 = np.float32(gain * (1 / scale))  # the library forms gain / 128 in double and rounds once
+        x = ((first.astype(np.float32) - np.float32(off)) * g32 + 1j * ((second.astype(np.float32) - np.float32(off)) * g32)).astype(np.complex64)
+        bufs = [P.DeviceBuffer.from_array(raw[k * n:(k + 1) * n], 0) for k in range(K)]
+        try:
+            for k in range(K):
+                a.process_raw_device(bufs[k].ptr, n, fmt, order, gain)  # no synchronisation in between
+            a.synchronize()
+            ga = a.audio()
+        finally:
+            for bf in bufs:
+                bf.free()
+        for k in range(K):
+            gb = b.process(x[k * n:(k + 1) * n])[0]
+        assert ga.shape == gb.shape and np.abs(gb).max() > 1e-3
+        assert np.array_equal(ga, gb)
+        assert a.kernel_name(2) == "k_mix_dec_mfma"
+
+
 def test_pinned_ingest_slots_equal_process_raw(gpu_lib):
     """pebblegpu_receiver_ingest_acquire / _submit / pebblegpu_receiver_process_ingested (the library's pinned double buffer, SURVEY 8b:
     the producer of hackrfdevice.cpp:533-566 fills the slot instead of its own ring): six batches of HackRF int8 pairs at the
