@@ -203,7 +203,12 @@ const void *pebblegpu_receiver_zoom_spectrum(const pebblegpu_receiver *rx, uint6
  * updates and, for raw input that is staged, its conversion pass), or to the pebblegpu_receiver_synchronize /
  * timing query that closes it -- back to back the sum over calls is the wall time, a single call's figure
  * includes whatever the host let pass before it queued the next one.  PEBBLEGPU_EVENTS=full (read when the
- * receiver is created) gives every call an end event of its own. */
+ * receiver is created) gives every call an end event of its own.
+ * A receiver WITHOUT a display transform (spectrum_bins = 0) runs a call in two stages on two streams -- mixer + decimator, then
+ * band-pass .. resampler -- the second beside the NEXT call's first when calls are queued back to back: which = 0 of such a call
+ * runs from the end of the previous call's first stage to the end of its own second stage (its latency; back to back the calls
+ * overlap, so the figures sum to more than the wall time).  PEBBLEGPU_BANK_PIPELINE=0 (read when the receiver is created) keeps
+ * every call on one stream; set_profiling(rx, 1) does the same for as long as it is on. */
 int pebblegpu_receiver_last_ms(const pebblegpu_receiver *rx, int which, float *ms);
 /* name(s) of the kernel(s) behind group `which` (1..5) as the last process call ran them ("" when the group is empty): the
  * bench labels its per-kernel roofline lines with these */
