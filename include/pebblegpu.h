@@ -327,6 +327,31 @@ int pebblegpu_decimator_dec_by2_stages(const pebblegpu_decimator *d, uint32_t *s
  * see DESIGN.md section 4. */
 int pebblegpu_decimator_process(pebblegpu_decimator *d, const double *in, double *out, uint32_t n, uint32_t *n_out);
 
+typedef struct pebblegpu_downconvert pebblegpu_downconvert;
+/* CDownConvert (pebblelib/downconvert.h:25-50, downconvert.cpp): the alternate mixer + decimator -- a quadrature oscillator
+ * (the same recurrence as Mixer, but SetFrequency keeps its phasor and there is no "frequency 0 returns the input" exit) and a
+ * cascade of decimate-by-2 stages picked per octave: CIC3, a fixed 11-tap halfband, 15..51-tap halfbands whose DecBy2 counts
+ * tap 0 twice (downconvert.cpp:368-376: reproduced).  max_in_length: the largest InLength a ProcessData call will pass. */
+int pebblegpu_downconvert_create(int device, uint32_t max_in_length, pebblegpu_downconvert **out);
+int pebblegpu_downconvert_destroy(pebblegpu_downconvert *d);
+/* TYPEREAL SetDataRate(InRate, MaxBW) (simple = 0, downconvert.cpp:139-206) / SetDataRateSimple (simple = 1, :213-237): builds
+ * the stage list when either argument changed, returns the output rate.  As in the reference the call ends with
+ * SetFrequency(m_NcoFreq) on the STORED frequency, which mirrors an earlier tuning (call it first, as receiver.cpp:198 does).
+ * More than nine stages (the reference's pointer array holds ten entries including the terminating NULL): E_UNSUPPORTED. */
+int pebblegpu_downconvert_set_data_rate(pebblegpu_downconvert *d, double in_rate, double max_bw, int simple, double *out_rate);
+int pebblegpu_downconvert_set_frequency(pebblegpu_downconvert *d, double nco_freq);   /* SetFrequency, downconvert.cpp:100-112 */
+int pebblegpu_downconvert_set_cw_offset(pebblegpu_downconvert *d, double offset);     /* SetCwOffset, downconvert.h:34 */
+/* the stage list: taps[j] = tap count of stage j, 0 for the CIC3 */
+int pebblegpu_downconvert_stages(const pebblegpu_downconvert *d, uint32_t *n_stages, uint32_t *taps, uint32_t taps_cap);
+/* int ProcessData(int InLength, TYPECPX *pInData, TYPECPX *pOutData), downconvert.cpp:250-335: InLength a multiple of 2^stages;
+ * returns the output count in *n_out.  The input is NOT modified (the reference mixes it in place).  Streams with exact history for
+ * any such InLength: a call that leaves a stage fewer samples than it has taps is not skipped as the reference's "safety net" does
+ * (:361-362, which returns stale samples). */
+int pebblegpu_downconvert_process(pebblegpu_downconvert *d, uint32_t in_length, const double *in, double *out, uint32_t *n_out);
+/* the same on device buffers (float2 in; *d_out: library-owned float2 row, valid until the next call); queues and returns */
+int pebblegpu_downconvert_process_device(pebblegpu_downconvert *d, const void *d_iq, uint32_t in_length, const void **d_out, uint32_t *n_out);
+int pebblegpu_downconvert_synchronize(pebblegpu_downconvert *d);
+
 typedef struct pebblegpu_fastfir pebblegpu_fastfir;
 /* CFastFIR::CFastFIR, fastfir.cpp:77-145 (fft/fir sizes are #defines there; 0,0 -> 2048,1025) */
 int pebblegpu_fastfir_create(int device, uint32_t fft_size, uint32_t fir_size, pebblegpu_fastfir **out);

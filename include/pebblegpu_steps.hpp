@@ -117,6 +117,42 @@ private:
     int status = 0;
 };
 
+// CDownConvert (pebblelib/downconvert.h:25-50): same member names and argument meaning; TYPECPX = CPX
+class CDownConvert {
+public:
+    explicit CDownConvert(uint32_t maxInLength = 65536, int device = 0) { status = report("downconvert_create", pebblegpu_downconvert_create(device, maxInLength, &h)); }
+    ~CDownConvert() { pebblegpu_downconvert_destroy(h); }
+    CDownConvert(const CDownConvert &) = delete;
+    CDownConvert &operator=(const CDownConvert &) = delete;
+    void SetFrequency(double NcoFreq) { if (h) status = report("downconvert_set_frequency", pebblegpu_downconvert_set_frequency(h, NcoFreq)); }
+    void SetCwOffset(double offset) { if (h) status = report("downconvert_set_cw_offset", pebblegpu_downconvert_set_cw_offset(h, offset)); }
+    double SetDataRate(double InRate, double MaxBW)
+    {
+        double r = InRate;
+        if (h) status = report("downconvert_set_data_rate", pebblegpu_downconvert_set_data_rate(h, InRate, MaxBW, 0, &r));
+        return r;
+    }
+    double SetDataRateSimple(double InRate, double MaxBW)
+    {
+        double r = InRate;
+        if (h) status = report("downconvert_set_data_rate", pebblegpu_downconvert_set_data_rate(h, InRate, MaxBW, 1, &r));
+        return r;
+    }
+    // returns the number of samples written to pOutData; pInData is left as it was (the reference mixes it in place)
+    int ProcessData(int InLength, CPX *pInData, CPX *pOutData)
+    {
+        uint32_t n = 0;
+        if (!h || InLength <= 0) return 0;
+        status = report("downconvert_process", pebblegpu_downconvert_process(h, (uint32_t)InLength, reinterpret_cast<const double *>(pInData), reinterpret_cast<double *>(pOutData), &n));
+        return status ? 0 : (int)n;
+    }
+    int lastStatus() const { return status; }
+
+private:
+    pebblegpu_downconvert *h = nullptr;
+    int status = 0;
+};
+
 class CFastFIR {
 public:
     explicit CFastFIR(uint32_t fftSize = 0, uint32_t firSize = 0, int device = 0) { status = report("fastfir_create", pebblegpu_fastfir_create(device, fftSize, firSize, &h)); }

@@ -32,6 +32,15 @@ def lib():
     if _lib is None:
         build()
         L = C.CDLL(_SO)
+        L.po_downconvert_new.restype = C.c_void_p
+        L.po_downconvert_free.argtypes = [C.c_void_p]
+        L.po_downconvert_set_frequency.argtypes = [C.c_void_p, C.c_double]
+        L.po_downconvert_set_cw_offset.argtypes = [C.c_void_p, C.c_double]
+        L.po_downconvert_set_data_rate.restype = C.c_double
+        L.po_downconvert_set_data_rate.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.po_downconvert_chain_len.argtypes = [C.c_void_p]
+        L.po_downconvert_stage_taps.argtypes = [C.c_void_p, C.c_int]
+        L.po_downconvert_process.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.po_decimator_new.restype = C.c_void_p
         L.po_decimator_free.argtypes = [C.c_void_p]
         L.po_decimator_build.restype = C.c_double
@@ -185,6 +194,39 @@ class Decimator:
         x = _c128(x)
         out = np.empty(len(x) + 8, dtype=np.complex128)
         n = lib().po_decimator_process(self.h, _ptr(x), _ptr(out), C.c_uint32(len(x)))
+        return out[:n].copy()
+
+
+class DownConvert:
+    """pebblelib/downconvert.cpp (CDownConvert: quadrature-oscillator mixer + cascade of decimate-by-2 stages)"""
+
+    def __init__(self):
+        self.h = lib().po_downconvert_new()
+        self.rate = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().po_downconvert_free(self.h)
+            self.h = None
+
+    def set_data_rate(self, in_rate, max_bw, simple=False):
+        self.rate = lib().po_downconvert_set_data_rate(self.h, float(in_rate), float(max_bw), 1 if simple else 0)
+        return self.rate
+
+    def set_frequency(self, f):
+        lib().po_downconvert_set_frequency(self.h, float(f))
+
+    def set_cw_offset(self, off):
+        lib().po_downconvert_set_cw_offset(self.h, float(off))
+
+    def chain(self):
+        """tap counts of the stages, 0 = CIC3"""
+        return [lib().po_downconvert_stage_taps(self.h, i) for i in range(lib().po_downconvert_chain_len(self.h))]
+
+    def process(self, x):
+        x = _c128(x)
+        out = np.empty(len(x) + 8, dtype=np.complex128)
+        n = lib().po_downconvert_process(self.h, C.c_int(len(x)), _ptr(x), _ptr(out))
         return out[:n].copy()
 
 

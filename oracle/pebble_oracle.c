@@ -707,6 +707,159 @@ void po_demod_sam_process(po_demod_sam *d, const double *in, double *out, int n)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * CDownConvert -- pebblelib/downconvert.cpp, filtercoef.h.  TEST INFRASTRUCTURE like the rest of this file.
+ * ---------------------------------------------------------------------------------------------- */
+#include "dc_taps.h"
+#define PO_DC_MAX_STAGES 9       /* MAX_DECSTAGES 10 "one more than max" (downconvert.h:23): a tenth stage would overwrite the list's NULL */
+#define PO_DC_MIN_OUTPUT_RATE (7900.0 * 2.0) /* downconvert.cpp:58 */
+typedef struct {
+    int design;                  /* index into pebble_dc_designs; 0 = CCicN3DecimateBy2 */
+    int fixed11;                 /* CHalfBand11TapDecimateBy2 (no doubled tap) */
+    double hist[2 * 64];         /* the last ntaps - 1 inputs (m_pHBFirBuf[0 .. FirLength-2], d0..d9, m_Xeven / m_Xodd) */
+} po_dc_stage;
+struct po_downconvert {
+    double in_rate, max_bw, out_rate, nco_freq, nco_inc, cw_offset, osc_cos, osc_sin, osc1_re, osc1_im;
+    po_dc_stage st[PO_DC_MAX_STAGES];
+    int nst;
+    double *work;
+    int work_cap;
+};
+po_downconvert *po_downconvert_new(void) /* ctor, :63-77 */
+{
+    po_downconvert *d = (po_downconvert *)calloc(1, sizeof(*d));
+    d->in_rate = 100000.0;
+    d->max_bw = 10000.0;
+    d->osc1_re = 1.0;
+    return d;
+}
+void po_downconvert_free(po_downconvert *d)
+{
+    if (!d) return;
+    free(d->work);
+    free(d);
+}
+void po_downconvert_set_frequency(po_downconvert *d, double f) /* :100-112 */
+{
+    f = -f;
+    d->nco_freq = f + d->cw_offset;
+    d->nco_inc = PO_TWOPI * d->nco_freq / d->in_rate;
+    d->osc_cos = cos(d->nco_inc);
+    d->osc_sin = sin(d->nco_inc);
+}
+void po_downconvert_set_cw_offset(po_downconvert *d, double offset) { d->cw_offset = offset; }
+double po_downconvert_set_data_rate(po_downconvert *d, double in_rate, double max_bw, int simple)
+{
+    double f = in_rate;
+    if (d->in_rate != in_rate || d->max_bw != max_bw) { /* :143-144 / :217-218 */
+        d->in_rate = in_rate;
+        d->max_bw = max_bw;
+        memset(d->st, 0, sizeof(d->st));
+        d->nst = 0;
+        if (simple) { /* SetDataRateSimple, :224-229: HB51 until the rate is at or under 400 kHz */
+            while (f > 400000.0 && d->nst < PO_DC_MAX_STAGES) {
+                d->st[d->nst++].design = PEBBLE_DC_NDESIGNS - 1;
+                f /= 2.0;
+            }
+        } else {
+            const double last_max = pebble_dc_designs[PEBBLE_DC_NDESIGNS - 1].max_a - pebble_dc_designs[PEBBLE_DC_NDESIGNS - 1].max_b;
+            while (f > (d->max_bw / last_max) && f > PO_DC_MIN_OUTPUT_RATE && d->nst < PO_DC_MAX_STAGES) { /* :152 */
+                for (int k = 0; k < PEBBLE_DC_NDESIGNS; k++) { /* the ladder, :154-203: first design whose limit the rate clears */
+                    const double mx = pebble_dc_designs[k].max_a - pebble_dc_designs[k].max_b;
+                    if (f >= d->max_bw / mx) {
+                        d->st[d->nst].design = k;
+                        d->st[d->nst].fixed11 = (k == 1); /* :158-161: the unrolled 11-tap class, not the generic one */
+                        d->nst++;
+                        break;
+                    }
+                }
+                f /= 2.0;
+            }
+        }
+        d->out_rate = f;
+        /* SetFrequency(m_NcoFreq), :205 / :232, as written: the STORED (already negated, offset included) value goes through the
+         * negation and the offset once more -- a SetDataRate that changes anything flips the sign of the tuned frequency.
+         * Harmless in the reference's own order of calls (rate first, at 0 Hz; receiver.cpp:198, :718) */
+        po_downconvert_set_frequency(d, d->nco_freq);
+    }
+    return d->out_rate;
+}
+int po_downconvert_chain_len(const po_downconvert *d) { return d->nst; }
+int po_downconvert_stage_taps(const po_downconvert *d, int i) { return pebble_dc_designs[d->st[i].design].ntaps; }
+
+/* one DecBy2 over n complex samples in x (in place), returns n / 2 */
+static int po_dc_stage_run(po_dc_stage *s, int n, double *x)
+{
+    const int T = pebble_dc_designs[s->design].ntaps;
+    if (T == 0) { /* CCicN3DecimateBy2::DecBy2, :517-533; hist = {Xeven, Xodd} */
+        int j = 0;
+        for (int i = 0; i < n; i += 2, j++) {
+            const double er = x[2 * i], ei = x[2 * i + 1], odr = x[2 * i + 2], odi = x[2 * i + 3];
+            x[2 * j] = .125 * (odr + s->hist[0] + 3.0 * (s->hist[2] + er));
+            x[2 * j + 1] = .125 * (odi + s->hist[1] + 3.0 * (s->hist[3] + ei));
+            s->hist[2] = odr; s->hist[3] = odi;
+            s->hist[0] = er; s->hist[1] = ei;
+        }
+        return j;
+    }
+    const double *h = pebble_dc_designs[s->design].h;
+    if (n < T) return n / 2; /* "safety net", :361-362 (the 11-tap class has none: callers keep n >= 11) */
+    /* both halfband classes: buf = [T - 1 previous inputs | the n new ones], output i/2 from buf[i .. i + T - 1] */
+    double *buf = (double *)malloc((size_t)(n + T) * 2 * sizeof(double));
+    memcpy(buf, s->hist, (size_t)(T - 1) * 2 * sizeof(double));
+    memcpy(buf + 2 * (T - 1), x, (size_t)n * 2 * sizeof(double));
+    int no = 0;
+    for (int i = 0; i < n; i += 2) {
+        double ar, ai;
+        if (s->fixed11) { /* CHalfBand11TapDecimateBy2, :429-489: H0 H2 H4 H5 H6 H8 H10 in this order */
+            static const int idx[7] = {0, 2, 4, 5, 6, 8, 10};
+            ar = 0; ai = 0;
+            for (int q = 0; q < 7; q++) {
+                if (q == 0) { ar = h[0] * buf[2 * i]; ai = h[0] * buf[2 * i + 1]; }
+                else { ar += h[idx[q]] * buf[2 * (i + idx[q])]; ai += h[idx[q]] * buf[2 * (i + idx[q]) + 1]; }
+            }
+        } else { /* CHalfBandDecimateBy2::DecBy2, :368-384: tap 0 enters twice (the accumulator's start value AND j = 0) */
+            ar = buf[2 * i] * h[0];
+            ai = buf[2 * i + 1] * h[0];
+            for (int j = 0; j < T; j += 2) {
+                ar += buf[2 * (i + j)] * h[j];
+                ai += buf[2 * (i + j) + 1] * h[j];
+            }
+            ar += buf[2 * (i + (T - 1) / 2)] * h[(T - 1) / 2];
+            ai += buf[2 * (i + (T - 1) / 2) + 1] * h[(T - 1) / 2];
+        }
+        x[2 * no] = ar; x[2 * no + 1] = ai;
+        no++;
+    }
+    memcpy(s->hist, buf + 2 * n, (size_t)(T - 1) * 2 * sizeof(double)); /* the last T - 1 inputs, :386-390 / :491-495 */
+    free(buf);
+    return no;
+}
+
+int po_downconvert_process(po_downconvert *d, int n, const double *in, double *out) /* ProcessData, :250-335 */
+{
+    if (d->work_cap < n) {
+        free(d->work);
+        d->work = (double *)malloc((size_t)n * 2 * sizeof(double));
+        d->work_cap = n;
+    }
+    double *w = d->work;
+    for (int i = 0; i < n; i++) { /* NCO_OSC, :288-293 and the product :305-307 */
+        const double or_ = d->osc1_re * d->osc_cos - d->osc1_im * d->osc_sin;
+        const double oi = d->osc1_im * d->osc_cos + d->osc1_re * d->osc_sin;
+        const double gn = 1.95 - (d->osc1_re * d->osc1_re + d->osc1_im * d->osc1_im);
+        d->osc1_re = gn * or_;
+        d->osc1_im = gn * oi;
+        const double xr = in[2 * i], xi = in[2 * i + 1];
+        w[2 * i] = xr * or_ - xi * oi;
+        w[2 * i + 1] = xr * oi + xi * or_;
+    }
+    int m = n;
+    for (int j = 0; j < d->nst; j++) m = po_dc_stage_run(&d->st[j], m, w); /* :319-326 */
+    memcpy(out, w, (size_t)m * 2 * sizeof(double));
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * WFM mono demod -- application/demod/demod_wfm.cpp
  * ---------------------------------------------------------------------------------------------- */
 void po_demod_wfm_init(po_demod_wfm *d, double fs) /* init()+setSampleRate(), demod_wfm.cpp:100-196 */

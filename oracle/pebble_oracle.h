@@ -52,6 +52,20 @@ void po_decimator_stage(const po_decimator *d, int i, int *ntaps, uint32_t *stri
 /* Decimator::process (vDSP path): returns number of output samples (decimator.cpp:152-226) */
 uint32_t po_decimator_process(po_decimator *d, const double *in, double *out, uint32_t n);
 
+/* ---- CDownConvert: pebblelib/downconvert.cpp:63-535, filtercoef.h (the alternate mixer + decimator; "parity unpinned": the
+ * reference's tests hold no vector for it -- pinned only by the thresholds its own comments work out, downconvert.cpp:124-134) ---- */
+typedef struct po_downconvert po_downconvert;
+po_downconvert *po_downconvert_new(void);
+void po_downconvert_free(po_downconvert *d);
+void po_downconvert_set_frequency(po_downconvert *d, double f);      /* SetFrequency, :100-112 */
+void po_downconvert_set_cw_offset(po_downconvert *d, double offset); /* SetCwOffset, downconvert.h */
+/* SetDataRate (:139-206) / SetDataRateSimple (:213-237): returns the output rate */
+double po_downconvert_set_data_rate(po_downconvert *d, double in_rate, double max_bw, int simple);
+int po_downconvert_chain_len(const po_downconvert *d);
+int po_downconvert_stage_taps(const po_downconvert *d, int i);      /* 0 => CIC3 */
+/* ProcessData (:250-335): mixes a COPY of in[] (the reference mixes in place), returns the output count */
+int po_downconvert_process(po_downconvert *d, int n, const double *in, double *out);
+
 /* ---- plain DFT used by FastFIR and spectrum: Accelerate semantics, fftaccelerate.cpp:42-105 ----
  * dir=+1 forward e^{-j}, dir=-1 inverse e^{+j}; both unscaled; n power of two; in place. */
 void po_fft(double *x, uint32_t n, int dir);

@@ -9,9 +9,9 @@ from .binding import (  # noqa: F401
     PebbleGpuError, load_library, library_path, ReceiverBank, StreamBank, DeviceBuffer,
     DM_AM, DM_SAM, DM_FMN, DM_FMM, DM_FMS, DM_DSB, DM_LSB, DM_USB, DM_CWL, DM_CWU, DM_DIGL, DM_DIGU, DM_NONE,
 )
-from .steps import Mixer, Decimator, FastFIR, Demod, Spectrum  # noqa: F401
+from .steps import Mixer, Decimator, DownConvert, FastFIR, Demod, Spectrum  # noqa: F401
 
 __all__ = [
     "PebbleGpuError", "load_library", "library_path", "ReceiverBank", "StreamBank", "DeviceBuffer",
-    "Mixer", "Decimator", "FastFIR", "Demod", "Spectrum",
+    "Mixer", "Decimator", "DownConvert", "FastFIR", "Demod", "Spectrum",
 ]

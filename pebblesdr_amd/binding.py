@@ -24,6 +24,9 @@ SYMBOLS = [
     "pebblegpu_mixer_create", "pebblegpu_mixer_destroy", "pebblegpu_mixer_set_frequency", "pebblegpu_mixer_process",
     "pebblegpu_decimator_create", "pebblegpu_decimator_destroy", "pebblegpu_decimator_build_chain",
     "pebblegpu_decimator_dec_by2_stages", "pebblegpu_decimator_process",
+    "pebblegpu_downconvert_create", "pebblegpu_downconvert_destroy", "pebblegpu_downconvert_set_data_rate", "pebblegpu_downconvert_set_frequency",
+    "pebblegpu_downconvert_set_cw_offset", "pebblegpu_downconvert_stages", "pebblegpu_downconvert_process", "pebblegpu_downconvert_process_device",
+    "pebblegpu_downconvert_synchronize",
     "pebblegpu_fastfir_create", "pebblegpu_fastfir_destroy", "pebblegpu_fastfir_setup", "pebblegpu_fastfir_process",
     "pebblegpu_demod_create", "pebblegpu_demod_destroy", "pebblegpu_demod_set_mode", "pebblegpu_demod_set_bandwidth",
     "pebblegpu_demod_process",
@@ -134,6 +137,15 @@ def _declare(L):
     L.pebblegpu_decimator_build_chain.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_float)]
     L.pebblegpu_decimator_dec_by2_stages.argtypes = [vp, C.POINTER(u32)]
     L.pebblegpu_decimator_process.argtypes = [vp, dp, dp, u32, C.POINTER(u32)]
+    L.pebblegpu_downconvert_create.argtypes = [i32, u32, C.POINTER(vp)]
+    L.pebblegpu_downconvert_destroy.argtypes = [vp]
+    L.pebblegpu_downconvert_set_data_rate.argtypes = [vp, C.c_double, C.c_double, i32, C.POINTER(C.c_double)]
+    L.pebblegpu_downconvert_set_frequency.argtypes = [vp, C.c_double]
+    L.pebblegpu_downconvert_set_cw_offset.argtypes = [vp, C.c_double]
+    L.pebblegpu_downconvert_stages.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), u32]
+    L.pebblegpu_downconvert_process.argtypes = [vp, u32, dp, dp, C.POINTER(u32)]
+    L.pebblegpu_downconvert_process_device.argtypes = [vp, vp, u32, C.POINTER(vp), C.POINTER(u32)]
+    L.pebblegpu_downconvert_synchronize.argtypes = [vp]
     L.pebblegpu_fastfir_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
     L.pebblegpu_fastfir_destroy.argtypes = [vp]
     L.pebblegpu_fastfir_setup.argtypes = [vp, dbl, dbl, dbl, dbl]

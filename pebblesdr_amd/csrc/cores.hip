@@ -188,6 +188,16 @@ void OscBank::retune(uint32_t ch, double f)
     c.dirty = true;
     adv_stale = true;
 }
+// CDownConvert::SetFrequency (pebblelib/downconvert.cpp:100-112): a new increment for the oscillator as it stands -- phase and amplitude
+// recurrence go on (m_Osc1 is not touched), where Mixer::setFrequency starts over
+void OscBank::retune_keep(uint32_t ch, double f)
+{
+    Ctl &c = ctl[ch];
+    c.freq = f;
+    c.inc = (-f) / fs;
+    c.dirty = true;
+    adv_stale = true;
+}
 int OscBank::upload(hipStream_t s)
 {
     // retuned channels: rebuild the constant part (phasor step tables) and upload the whole block, synchronously (rare)
@@ -204,7 +214,7 @@ int OscBank::upload(hipStream_t s)
         ph -= std::floor(ph);
         o.step512 = make_float2((float)std::cos(design::kTwoPi * ph), (float)std::sin(design::kTwoPi * ph));
         o.inc = c.inc;
-        o.mix_on = (-c.freq) != 0 ? 1u : 0u;  // if (m_frequency == 0) return in;  (mixer.cpp:51-53)
+        o.mix_on = (force_mix || (-c.freq) != 0) ? 1u : 0u;  // if (m_frequency == 0) return in;  (mixer.cpp:51-53; CDownConvert has no such exit)
         o.phase0 = c.phase0;
         o.n0 = 0;
         PG_HIP(hipMemcpyAsync(d_osc + ch, &o, sizeof(ChanOsc), hipMemcpyHostToDevice, s));
@@ -1040,6 +1050,17 @@ int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdva
         if (jobs[i].hist > maxh) maxh = jobs[i].hist;
     }
     if (maxh > 256 * 32) return fail(PEBBLEGPU_E_UNSUPPORTED, "history of %d samples too deep for the tail refresh", maxh);
+    return 0;
+}
+// one strided real-tap FIR over `channels` rows (k_fir_dec with one tap set for all rows): y[o] = sum_p in[o stride + p - (ntaps - 1)] taps[p]
+int run_fir_dec(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n_out, int stride,
+                const float *d_taps, int ntaps, uint32_t channels)
+{
+    if (n_out <= 0) return 0;
+    if (ntaps < 1 || ntaps > kMaxTaps) return fail(PEBBLEGPU_E_UNSUPPORTED, "%d taps: k_fir_dec holds at most %d", ntaps, kMaxTaps);
+    launch(k_fir_dec, dim3(cdiv(n_out, 256), channels), dim3(256), s, in, in_pitch, out, out_pitch, n_out, stride, d_taps, (const float *)nullptr, 0,
+           (const int *)nullptr, ntaps, 1.0f, 0, (const int *)nullptr, Gate{nullptr, 0, 0});
+    PG_HIP(hipGetLastError());
     return 0;
 }
 int run_nap(hipStream_t s, unsigned ticks_100mhz)

@@ -2,6 +2,7 @@
 #include "design.h"
 #include <cmath>
 #include "hb_taps.inc"
+#include "dc_taps.inc"
 
 namespace pg {
 namespace design {
@@ -32,6 +33,39 @@ Chain build_chain(uint32_t fs_in, uint32_t protect_bw, uint32_t fs_out_min)
 }
 
 const double *halfband_taps(int design) { return pebble_hb_designs[design].h; }
+
+DcChain downconvert_chain(double in_rate, double max_bw, bool simple)
+{
+    DcChain c;
+    double f = in_rate;
+    if (simple) {  // SetDataRateSimple, downconvert.cpp:224-229
+        while (f > 400000.0) {
+            c.stages.push_back(PEBBLE_DC_NDESIGNS - 1);
+            f /= 2.0;
+        }
+    } else {
+        const double last = pebble_dc_designs[PEBBLE_DC_NDESIGNS - 1].max_a - pebble_dc_designs[PEBBLE_DC_NDESIGNS - 1].max_b;
+        while (f > (max_bw / last) && f > (7900.0 * 2.0)) {  // :152, MIN_OUTPUT_RATE :58
+            for (int k = 0; k < PEBBLE_DC_NDESIGNS; k++)
+                if (f >= max_bw / (pebble_dc_designs[k].max_a - pebble_dc_designs[k].max_b)) {  // the ladder, :154-203
+                    c.stages.push_back(k);
+                    break;
+                }
+            f /= 2.0;
+        }
+    }
+    c.out_rate = f;
+    return c;
+}
+int downconvert_stage_taps(int design) { return pebble_dc_designs[design].ntaps; }
+std::vector<double> downconvert_stage_response(int design)
+{
+    if (design == 0) return {0.125, 0.375, 0.375, 0.125};  // CCicN3DecimateBy2::DecBy2, :524-526
+    const int T = pebble_dc_designs[design].ntaps;
+    std::vector<double> h(pebble_dc_designs[design].h, pebble_dc_designs[design].h + T);
+    if (design != 1) h[0] += pebble_dc_designs[design].h[0];  // CHalfBandDecimateBy2::DecBy2: the accumulator starts from tap 0, the loop adds it again
+    return h;
+}
 
 void mixer_amplitudes(float *tab, int n, float *a_inf)
 {

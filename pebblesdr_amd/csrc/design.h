@@ -27,6 +27,18 @@ struct Chain {
 Chain build_chain(uint32_t fs_in, uint32_t protect_bw, uint32_t fs_out_min);
 const double *halfband_taps(int design);  // length = ntaps of that design
 
+// CDownConvert::SetDataRate / SetDataRateSimple (pebblelib/downconvert.cpp:139-237): the decimate-by-2 stages from the input rate down,
+// each an index into the stage table (dc_taps.inc: 0 = CIC3, 1 = the fixed 11-tap halfband, 2.. = hb15 .. hb51); returns the output rate
+struct DcChain {
+    std::vector<int> stages;
+    double out_rate = 0;
+};
+DcChain downconvert_chain(double in_rate, double max_bw, bool simple);
+int downconvert_stage_taps(int design);          // 0 for the CIC3
+// the taps a stage applies, oldest sample first: CIC3 -> (1 3 3 1) / 8 (ending on the pair's odd sample); the fixed 11-tap class -> its
+// table; the generic class -> its table with tap 0 counted twice (downconvert.cpp:368-376)
+std::vector<double> downconvert_stage_response(int design);
+
 // Mixer amplitude sequence a_0 = 1, a_{n+1} = a_n (1.95 - a_n^2)  (pebblelib/mixer.cpp:65-67); a_inf = sqrt(.95)
 void mixer_amplitudes(float *tab, int n, float *a_inf);
 

@@ -39,6 +39,8 @@ int make_twiddles_t128(float2 **d_tw);
 int make_twiddles_t128q(float2 **d_tw);  // four tables, the pruned transform's per-work-item factor folded in (k_spectrum_t128)
 int run_save_tails(hipStream_t s, const std::vector<TailJob> &jobs, uint32_t channels, const OscAdvance *oa = nullptr);
 int run_nap(hipStream_t s, unsigned ticks_100mhz);  // one sleeping wave (k_nap)
+int run_fir_dec(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n_out, int stride,
+                const float *d_taps, int ntaps, uint32_t channels);
 int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa);  // 0, or a failure code (too many / too deep)
 int run_normalize_iq(int fmt, int order, double gain, const void *d_src, long long n, float2 *d_dst, hipStream_t s, bool wait, const float *final_scale = nullptr);
 int run_gate_eval(hipStream_t s, const float4 *d_smeter, long long smeter_pitch, int frames_per_sf, int k, const float *d_squelch, unsigned char *d_gate,
@@ -77,6 +79,8 @@ struct OscBank {
     int init(uint32_t channels, double sample_rate);
     void release();
     void retune(uint32_t ch, double f);           // Mixer::setFrequency, mixer.cpp:25-40
+    void retune_keep(uint32_t ch, double f);      // CDownConvert::SetFrequency, downconvert.cpp:100-112: phase and amplitude carry on
+    bool force_mix = false;                       // no "frequency 0 returns the input" exit (CDownConvert always multiplies)
     int upload(hipStream_t s);                     // refresh the device blocks (async, from pinned staging)
     void advance(uint64_t n);                      // after a call consumed n samples
     bool any_transient() const;                    // some oscillator is inside its amplitude transient (n0 < kAmpTab)

@@ -61,6 +61,24 @@ struct pebblegpu_decimator : pg::StepBase {
     pg::DecimCore dec;
     float2 *d_in = nullptr;
 };
+// CDownConvert (pebblelib/downconvert.cpp): quadrature-oscillator mixer + a cascade of decimate-by-2 stages
+struct pebblegpu_downconvert : pg::StepBase {
+    uint32_t cap = 0;
+    double in_rate = 100000.0, max_bw = 10000.0, out_rate = 0, nco_freq = 0, cw_offset = 0;  // ctor values, downconvert.cpp:63-77
+    bool rate_set = false;
+    pg::OscBank osc;
+    std::vector<int> stages;          // indices into the stage table
+    std::vector<pg::HistBuf> bufs;    // bufs[j]: input of stage j (head-room = its look-back); bufs[nst]: the result
+    std::vector<float *> d_taps;      // [stage] the response it applies, oldest sample first
+    std::vector<int> ntaps;
+    float2 *d_in = nullptr;
+    void drop_chain()
+    {
+        for (auto &b : bufs) b.release();
+        for (float *t : d_taps) if (t) (void)hipFree(t);
+        bufs.clear(); d_taps.clear(); ntaps.clear(); stages.clear();
+    }
+};
 struct pebblegpu_fastfir : pg::StepBase {
     pg::FastFirCore ff;
     pg::HistBuf in;
@@ -212,6 +230,153 @@ int pebblegpu_decimator_process(pebblegpu_decimator *d, const double *in, double
     }
     PG_HIP(hipStreamSynchronize(d->stream));
     *n_out = (uint32_t)no;
+    return 0;
+}
+
+// ---------------- CDownConvert ----------------
+int pebblegpu_downconvert_create(int device, uint32_t max_in_length, pebblegpu_downconvert **out)
+{
+    if (!out || !max_in_length) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    if (int rc = step_device(device)) return rc;
+    pebblegpu_downconvert *d = new (std::nothrow) pebblegpu_downconvert();
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "out of host memory");
+    d->cap = max_in_length;
+    int rc = d->open(device);
+    if (!rc) rc = d->osc.init(1, d->in_rate);
+    if (!rc && hipMalloc((void **)&d->d_in, sizeof(float2) * max_in_length) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
+    if (rc) { pebblegpu_downconvert_destroy(d); return rc; }
+    d->osc.force_mix = true;       // no "frequency 0" exit: ProcessData always multiplies (downconvert.cpp:283-308)
+    d->osc.retune(0, 0.0);         // m_Osc1 = (1, 0), m_NcoFreq = 0 (ctor)
+    *out = d;
+    return 0;
+}
+int pebblegpu_downconvert_destroy(pebblegpu_downconvert *d)
+{
+    if (!d) return 0;
+    d->close_stream();
+    d->osc.release();
+    d->drop_chain();
+    if (d->d_in) (void)hipFree(d->d_in);
+    delete d;
+    return 0;
+}
+static int downconvert_tune(pebblegpu_downconvert *d, double f)  // SetFrequency, downconvert.cpp:100-112
+{
+    d->nco_freq = -f + d->cw_offset;
+    d->osc.retune_keep(0, -d->nco_freq);  // (OscBank negates as Mixer does: inc = -f / Fs)
+    return 0;
+}
+int pebblegpu_downconvert_set_frequency(pebblegpu_downconvert *d, double f)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return downconvert_tune(d, f);
+}
+int pebblegpu_downconvert_set_cw_offset(pebblegpu_downconvert *d, double offset)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    d->cw_offset = offset;  // SetCwOffset (downconvert.h:34): takes effect at the next SetFrequency
+    return 0;
+}
+int pebblegpu_downconvert_set_data_rate(pebblegpu_downconvert *d, double in_rate, double max_bw, int simple, double *out_rate)
+{
+    if (!d || !(in_rate > 0) || !(max_bw > 0)) return fail(PEBBLEGPU_E_INVALID, "bad argument");
+    PG_HIP(hipSetDevice(d->device));
+    if (!d->rate_set || d->in_rate != in_rate || d->max_bw != max_bw) {  // :143-144 / :217-218
+        const pg::design::DcChain c = pg::design::downconvert_chain(in_rate, max_bw, simple != 0);
+        // MAX_DECSTAGES 10, "one more than max" (downconvert.h:23): a tenth stage overwrites the list's terminating NULL in the reference
+        if (c.stages.size() > 9) return fail(PEBBLEGPU_E_UNSUPPORTED, "%zu decimate-by-2 stages: CDownConvert holds nine", c.stages.size());
+        PG_HIP(hipStreamSynchronize(d->stream));
+        d->drop_chain();
+        d->in_rate = in_rate;
+        d->max_bw = max_bw;
+        d->out_rate = c.out_rate;
+        d->stages = c.stages;
+        long long len = d->cap;
+        for (size_t j = 0; j <= c.stages.size(); j++) {
+            int look = 4;
+            if (j < c.stages.size()) {
+                const std::vector<double> h = pg::design::downconvert_stage_response(c.stages[j]);
+                look = (int)h.size() + 1;
+                std::vector<float> hf(h.begin(), h.end());
+                float *t = nullptr;
+                PG_HIP(hipMalloc((void **)&t, sizeof(float) * hf.size()));
+                d->d_taps.push_back(t);
+                d->ntaps.push_back((int)hf.size());
+                PG_HIP(hipMemcpy(t, hf.data(), sizeof(float) * hf.size(), hipMemcpyHostToDevice));
+            }
+            pg::HistBuf b;
+            if (int rc = b.alloc(1, look, len + 2)) return rc;
+            d->bufs.push_back(b);
+            len /= 2;
+        }
+        // the oscillator keeps its phasor; its increment follows the new input rate
+        d->osc.fs = in_rate;
+        d->rate_set = true;
+        // SetFrequency(m_NcoFreq), :205 / :232, as written: the STORED value (negated, offset included) is negated once more
+        downconvert_tune(d, d->nco_freq);
+    }
+    if (out_rate) *out_rate = d->out_rate;
+    return 0;
+}
+int pebblegpu_downconvert_stages(const pebblegpu_downconvert *d, uint32_t *n_stages, uint32_t *taps, uint32_t taps_cap)
+{
+    if (!d || !n_stages) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    *n_stages = (uint32_t)d->stages.size();
+    for (size_t j = 0; taps && j < d->stages.size() && j < taps_cap; j++) taps[j] = (uint32_t)pg::design::downconvert_stage_taps(d->stages[j]);
+    return 0;
+}
+// queues mixer + stages on the step's stream; *d_out / *n_out: the result row (device, valid until the next call)
+static int downconvert_run(pebblegpu_downconvert *d, const float2 *d_x, uint32_t n, const float2 **d_out, uint32_t *n_out)
+{
+    if (!d->rate_set) return fail(PEBBLEGPU_E_INVALID, "SetDataRate first");
+    const size_t nst = d->stages.size();
+    if (n > d->cap) return fail(PEBBLEGPU_E_SIZE, "%u samples exceed the %u this object was created for", n, d->cap);
+    if (n == 0 || (n & ((1u << nst) - 1)) != 0) return fail(PEBBLEGPU_E_SIZE, "InLength must be a multiple of 2^%zu (downconvert.cpp:246-247)", nst);
+    if (int rc = d->osc.upload(d->stream)) return rc;
+    if (int rc = pg::run_mixer(d->stream, d_x, d->bufs[0].data(), (long long)n, d->osc)) return rc;
+    std::vector<pg::TailJob> jobs;
+    long long len = n;
+    for (size_t j = 0; j < nst; j++) {
+        // the CIC3's newest tap is the pair's ODD sample: the same strided FIR read one sample later
+        const float2 *src = d->bufs[j].data() + (d->stages[j] == 0 ? 1 : 0);
+        if (int rc = pg::run_fir_dec(d->stream, src, d->bufs[j].pitch, d->bufs[j + 1].data(), d->bufs[j + 1].pitch, len / 2, 2, d->d_taps[j], d->ntaps[j], 1)) return rc;
+        jobs.push_back(pg::TailJob{d->bufs[j].data(), d->bufs[j].pitch, len, d->bufs[j].hist, 0, nullptr, 0});
+        len /= 2;
+    }
+    if (int rc = pg::run_save_tails(d->stream, jobs, 1)) return rc;
+    d->osc.advance(n);
+    *d_out = d->bufs[nst].data();
+    *n_out = (uint32_t)len;
+    return 0;
+}
+int pebblegpu_downconvert_process(pebblegpu_downconvert *d, uint32_t in_length, const double *in, double *out, uint32_t *n_out)
+{
+    if (!d || !in || !out || !n_out) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    PG_HIP(hipSetDevice(d->device));
+    if (in_length > d->cap) return fail(PEBBLEGPU_E_SIZE, "%u samples exceed the %u this object was created for", in_length, d->cap);
+    if (int rc = d->up(d->d_in, in, in_length)) return rc;
+    const float2 *res = nullptr;
+    uint32_t no = 0;
+    if (int rc = downconvert_run(d, d->d_in, in_length, &res, &no)) return rc;
+    if (int rc = d->down(out, res, no)) return rc;
+    PG_HIP(hipStreamSynchronize(d->stream));
+    *n_out = no;
+    return 0;
+}
+int pebblegpu_downconvert_process_device(pebblegpu_downconvert *d, const void *d_iq, uint32_t in_length, const void **d_out, uint32_t *n_out)
+{
+    if (!d || !d_iq || !d_out || !n_out) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    PG_HIP(hipSetDevice(d->device));
+    const float2 *res = nullptr;
+    if (int rc = downconvert_run(d, (const float2 *)d_iq, in_length, &res, n_out)) return rc;
+    *d_out = res;
+    return 0;
+}
+int pebblegpu_downconvert_synchronize(pebblegpu_downconvert *d)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    PG_HIP(hipSetDevice(d->device));
+    PG_HIP(hipStreamSynchronize(d->stream));
     return 0;
 }
 

@@ -80,6 +80,43 @@ class Decimator(_Step):
         return out[: n.value].copy()
 
 
+class DownConvert(_Step):
+    """CDownConvert (pebblelib/downconvert.h:25-50)"""
+    _destroy = "pebblegpu_downconvert_destroy"
+
+    def __init__(self, max_in_length=65536, device=0, lib=None):
+        self.L = lib or load_library()
+        self.h = C.c_void_p()
+        check(self.L, self.L.pebblegpu_downconvert_create(device, int(max_in_length), C.byref(self.h)))
+
+    def SetDataRate(self, in_rate, max_bw, simple=False):
+        r = C.c_double()
+        check(self.L, self.L.pebblegpu_downconvert_set_data_rate(self.h, float(in_rate), float(max_bw), 1 if simple else 0, C.byref(r)))
+        return r.value
+
+    def SetDataRateSimple(self, in_rate, max_bw):
+        return self.SetDataRate(in_rate, max_bw, True)
+
+    def SetFrequency(self, f):
+        check(self.L, self.L.pebblegpu_downconvert_set_frequency(self.h, float(f)))
+
+    def SetCwOffset(self, off):
+        check(self.L, self.L.pebblegpu_downconvert_set_cw_offset(self.h, float(off)))
+
+    def stages(self):
+        n = C.c_uint32()
+        taps = (C.c_uint32 * 16)()
+        check(self.L, self.L.pebblegpu_downconvert_stages(self.h, C.byref(n), taps, 16))
+        return [int(taps[i]) for i in range(n.value)]
+
+    def ProcessData(self, x):
+        x = _c128(x)
+        out = np.empty(len(x), dtype=np.complex128)
+        n = C.c_uint32()
+        check(self.L, self.L.pebblegpu_downconvert_process(self.h, len(x), x.ctypes.data_as(_dp), out.ctypes.data_as(_dp), C.byref(n)))
+        return out[: n.value].copy()
+
+
 class FastFIR(_Step):
     _destroy = "pebblegpu_fastfir_destroy"
 

@@ -528,3 +528,96 @@ def test_agc_remembers_the_silence_it_started_in(oracle_mod):
     assert rr(2) < 1e-7          # while the attack average rules the gain, nothing shows
     assert rr(5) > 3e-6          # 160-190 ms in: the decay average, seeded at start-up, now does
     assert rr(15) < rr(5) / 10   # and its trace fades (half a second in: below 1e-6)
+
+
+def _dc_table():
+    """(name, ntaps, limit, taps) rows of oracle/dc_taps.h -- the data table the oracle and the library both carry"""
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "dc_taps.h")).read()
+    rows = []
+    for m in re.finditer(r'\{"(\w+)",\s*(\d+),\s*([0-9.]+),\s*([0-9.]+),\s*\{([^}]*)\}\}', txt):
+        vals = [float(v) for v in m.group(5).replace("\n", " ").split(",") if v.strip()]
+        rows.append((m.group(1), int(m.group(2)), float(m.group(3)) - float(m.group(4)), vals[:int(m.group(2))]))
+    assert len(rows) == 12
+    return rows
+
+
+def test_downconvert_stage_limits_are_the_reference_comments(oracle_mod):
+    """CDownConvert (pebblelib/downconvert.cpp): the reference works the stage limits out in a comment above SetDataRate
+    (:124-134, "Examples at 48k 10k"): CIC3 to 32,000,000, the 11-tap halfband to 1,920,000, HB15 979,592, HB19 666,666, HB23 527,472
+    and, for HB51, 287,425 at 48 kHz and 59,880 at 10 kHz of wanted bandwidth.  The generated table (filtercoef.h:19-30 through
+    tools/gen_dc_taps.py) reproduces every one of those figures, and the ladder picks a stage exactly at its limit."""
+    rows = {r[0]: r for r in _dc_table()}
+    for name, bw, want in (("cic3", 48000, 32000000), ("hb11", 48000, 1920000), ("hb15", 48000, 979592), ("hb19", 48000, 666666),
+                           ("hb23", 48000, 527472), ("hb51", 48000, 287425), ("hb51", 10000, 59880)):
+        assert abs(bw / rows[name][2] - want) < 1.0, (name, bw / rows[name][2])  # (the comment rounds some and truncates others)
+    # the ladder: the FIRST design whose limit the rate clears; stops once the rate is at or under max_bw / HB51's limit or 15.8 kHz
+    d = oracle_mod.DownConvert()
+    assert d.set_data_rate(32000000.0, 48000) == 250000.0 and d.chain()[0] == 0 and len(d.chain()) == 7  # at CIC3's limit: CIC3; down to <= 287,425
+    d = oracle_mod.DownConvert()
+    assert d.set_data_rate(31999999.0, 48000) and d.chain()[0] == 11                            # just under: the 11-tap halfband
+    d = oracle_mod.DownConvert()
+    assert d.set_data_rate(2048000, 15000) == 64000.0 and d.chain() == [11, 11, 15, 19, 31]      # receiver.cpp:198 at the stock rate
+    d = oracle_mod.DownConvert()
+    assert d.set_data_rate(20e6, 200000, simple=True) == 312500.0 and d.chain() == [51] * 6      # receiver.cpp:217: HB51 down to <= 400 kHz
+    d = oracle_mod.DownConvert()
+    assert d.set_data_rate(40000, 15000) == 40000 and d.chain() == []                            # already under 15000 / 0.167: no stage
+
+
+def test_downconvert_against_independent_filters(oracle_mod):
+    """parity unpinned (the reference holds no vector for CDownConvert): the restatement against an independent model -- the
+    oscillator in closed form (a_0 = 1, a_{n+1} = a_n (1.95 - a_n^2), phase (n + 1) inc: the recurrence of downconvert.cpp:288-293
+    started from m_Osc1 = 1), every stage as a plain convolution at stride 2: the CIC3 as (1 3 3 1) / 8 ending on the pair's ODD sample
+    (:524-526), the fixed 11-tap class with its table as it stands (:429-489), the generic class with tap 0 counted twice
+    (:368-376: the accumulator starts from tap 0 and the loop adds it again).  Streaming: any split of the input into calls gives
+    the same output (each stage keeps its last ntaps - 1 inputs)."""
+    O = oracle_mod
+    rows = _dc_table()
+    by_taps = {r[1]: r for r in rows}
+    fs, f0 = 10e6, 1.234e6
+    d = O.DownConvert()
+    rate = d.set_data_rate(fs, 15000)
+    chain = d.chain()
+    assert chain == [0, 11, 11, 11, 11, 15, 27] and rate == fs / 128
+    d.set_frequency(f0)
+    n = 128 * 600
+    x = tones(fs, n, [(0.3, f0 + 2500.0), (0.2, f0 - 4000.0), (0.3, f0 + 900e3)]) + lcg_noise(n, 4, 1e-3)
+    got = np.concatenate([d.process(x[:128 * 100]), d.process(x[128 * 100:128 * 140]), d.process(x[128 * 140:])])  # (every stage sees >= its tap count per call: below that the reference returns early, :361-362)
+    one = O.DownConvert(); one.set_data_rate(fs, 15000); one.set_frequency(f0)
+    assert np.array_equal(got, one.process(x))
+    # the independent model
+    a = np.empty(n)
+    v = 1.0
+    for i in range(n):
+        a[i] = v
+        v = v * (1.95 - v * v)
+    inc = 2 * np.pi * (-f0) / fs
+    y = x * a * np.exp(1j * inc * (np.arange(n) + 1))
+    for taps in chain:
+        if taps == 0:
+            h = np.array([1, 3, 3, 1]) / 8.0
+            full = np.convolve(np.concatenate([np.zeros(3), y]), h)[3:]   # full[m] = sum_t h[t] y[m - t]
+            y = full[1::2][:len(y) // 2]                                  # ends on the odd sample 2 j + 1
+        else:
+            h = np.array(by_taps[taps][3])
+            if taps != 11:
+                h = h.copy(); h[0] *= 2.0
+            full = np.convolve(y, h[::-1])      # out[k] = sum_j h[j] y[2 k + j - (T - 1)]  ==  conv(y, reversed h)[2 k]
+            y = full[0:len(y):2]
+    assert got.shape == y.shape
+    assert np.sqrt(np.mean(np.abs(got - y) ** 2)) <= 1e-10 * np.sqrt(np.mean(np.abs(y) ** 2))  # (measured 2e-12: the recurrence against the closed form)
+    assert np.abs(got[300:]).max() > 0.2
+
+
+def test_downconvert_set_data_rate_flips_the_tuned_frequency(oracle_mod):
+    """As written (downconvert.cpp:205, :232): SetDataRate ends with SetFrequency(m_NcoFreq) -- the STORED frequency, which
+    SetFrequency negated when it stored it (:103-106), is negated again: a rate change after tuning mirrors the tuning.  The
+    reference's own call order (rates at construction, frequency later: receiver.cpp:198, :718) never shows it; restated, not fixed."""
+    O = oracle_mod
+    fs, f0, n = 2048000.0, 100e3, 64 * 400
+    x = tones(fs, n, [(0.5, f0 + 1000.0)])
+    a = O.DownConvert(); a.set_data_rate(fs, 15000); a.set_frequency(f0)
+    ya = a.process(x)
+    b = O.DownConvert(); b.set_frequency(f0); b.set_data_rate(fs, 15000)     # the other order: tuned to -f0 afterwards
+    yb = b.process(x)
+    assert np.abs(ya[200:]).min() > 0.4 and np.abs(yb[200:]).max() < 1e-3

@@ -2093,3 +2093,63 @@ def test_decimator_inside_the_display_transform_switches_routes_with_a_retune(gp
         assert np.array_equal(sa, sb), "call %d" % k
     fused = "k_spectrum_t128 (decimator inside)"
     assert routes[0] != fused and routes[1] == fused and routes[2] == fused and routes[3] != fused and routes[4] == fused and routes[5] == fused
+
+
+@pytest.mark.parametrize("fs,bw,simple,chain", [(2048000.0, 15000.0, False, [11, 11, 15, 19, 31]),       # receiver.cpp:198 at the stock rate
+                                                 (10e6, 15000.0, False, [0, 11, 11, 11, 11, 15, 27]),      # a CIC3 in front
+                                                 (20e6, 200000.0, True, [51] * 6),                         # receiver.cpp:217: the WFM chain
+                                                 (250000.0, 48000.0, False, [])])                          # under HB51's limit: oscillator only
+def test_downconvert_step_against_the_oracle(gpu_lib, oracle_mod, fs, bw, simple, chain):
+    """CDownConvert (pebblelib/downconvert.cpp), the alternate mixer + decimator: pebblegpu_downconvert_* against the oracle's
+    restatement -- the quadrature oscillator with its amplitude transient and its phase carried across calls AND across a retune
+    (SetFrequency keeps m_Osc1; there is no "frequency 0" exit), the CIC3 ending on the pair's odd sample, the fixed 11-tap
+    halfband, the generic halfband with tap 0 counted twice -- four calls of unequal length (the first inside the transient), a retune
+    and a CW offset before the third, frequency 0 for the fourth.  Oracle: parity unpinned (tests/test_oracle_pins.py pins its stage
+    limits to the reference's comments and checks it against an independent model)."""
+    import pebblesdr_amd as P
+    D = 1 << len(chain)
+    lens = [D * 600, D * 256, D * 1024, D * 300]
+    dc = P.DownConvert(max(lens))
+    ref = oracle_mod.DownConvert()
+    assert dc.SetDataRate(fs, bw, simple) == ref.set_data_rate(fs, bw, simple) == fs / D
+    assert dc.stages() == ref.chain() == chain
+    f0 = 0.11 * fs
+    dc.SetFrequency(f0); ref.set_frequency(f0)
+    n = sum(lens)
+    x = tones(fs, n, [(0.3, f0 + 0.02 * fs / D), (0.2, f0 - 0.05 * fs / D), (0.3, f0 + 0.37 * fs), (0.1, 0.013 * fs / D)]) + lcg_noise(n, 4, 1e-3)
+    off = 0
+    for k, m in enumerate(lens):
+        if k == 2:
+            dc.SetCwOffset(700.0); ref.set_cw_offset(700.0)
+            dc.SetFrequency(f0 + 0.01 * fs / D); ref.set_frequency(f0 + 0.01 * fs / D)
+        if k == 3:
+            dc.SetCwOffset(0.0); ref.set_cw_offset(0.0)
+            dc.SetFrequency(0.0); ref.set_frequency(0.0)
+        g = dc.ProcessData(x[off:off + m])
+        r = ref.process(x[off:off + m])
+        off += m
+        assert g.shape == r.shape == (m // D,)
+        assert rel_rms(g, r) <= TOL, (k, chain)
+        assert np.abs(r).max() > 0.05
+    with pytest.raises(P.PebbleGpuError):
+        dc.ProcessData(x[:max(lens) + D])        # beyond the size it was created for
+    if D > 1:
+        with pytest.raises(P.PebbleGpuError):
+            dc.ProcessData(x[:D * 600 + 1])      # not a multiple of 2^stages
+    with pytest.raises(P.PebbleGpuError):
+        P.DownConvert(1024).SetDataRate(100e6, 15000.0)   # eleven stages: the reference's list holds nine
+
+
+def test_downconvert_rate_change_mirrors_the_tuning_as_the_reference_does(gpu_lib, oracle_mod):
+    """SetDataRate ends with SetFrequency(m_NcoFreq) on the stored, already negated frequency (downconvert.cpp:205): tuned first and
+    given its rates afterwards the object sits on the mirror frequency.  Reproduced (the oracle test of the same name shows it)."""
+    import pebblesdr_amd as P
+    fs, f0, n = 2048000.0, 100e3, 32 * 800
+    x = tones(fs, n, [(0.5, f0 + 1000.0)])
+    a = P.DownConvert(n); a.SetDataRate(fs, 15000.0); a.SetFrequency(f0)
+    b = P.DownConvert(n); b.SetFrequency(f0); b.SetDataRate(fs, 15000.0)
+    rb = oracle_mod.DownConvert(); rb.set_frequency(f0); rb.set_data_rate(fs, 15000.0)
+    ya, yb = a.ProcessData(x), b.ProcessData(x)
+    assert np.abs(ya[200:]).min() > 0.4 and np.abs(yb[200:]).max() < 1e-3
+    want = rb.process(x)
+    assert np.sqrt(np.mean(np.abs(yb - want) ** 2)) <= 2e-7 * 0.5   # (an empty band: the error against the INPUT's level, as everywhere)
