@@ -144,13 +144,14 @@ int pebblegpu_set_mixer_freq(pebblegpu_receiver *rx, uint32_t channel, double fr
 int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_hz, double hi_hz);
 /* Receiver::demodModeChanged -> Demod::setDemodMode (receiver.cpp:640-655).  Narrow banks accept AM, SAM, FMN and
  * every pass-through mode (DSB/LSB/USB/CWL/CWU/DIGL/DIGU/NONE); WFM banks accept FMM (mono) and FMS.
- * FMS returns what Demod_WFM::processDataStereo (demod_wfm.cpp:255-365) delivers once its pilot PLL has dropped out, which it
- * does within the first blocks on every input it has been tried on (the phase detector of processPilotPll, :390-430 / :792-821,
- * is discontinuous at the loop's operating point; pinned on the oracle's line-by-line restatement with clean, noisy and absent
- * pilots at the demodulator rates the receiver runs, tests/test_oracle_pins.py -- other inputs: parity unpinned): the discriminator
- * output WITHOUT processDataMono's 75 kHz pre-filter, low-passed, de-emphasised and notched, the same signal in both
- * channels.  Not reproduced: the blocks before the drop-out (at most the first three of a stream, where the reference
- * demultiplexes with an unsettled pilot phase) and the RDS bit decoder (GUI text). */
+ * FMS is Demod_WFM::processDataStereo (demod_wfm.cpp:255-365): the discriminator output WITHOUT processDataMono's 75 kHz
+ * pre-filter, low-passed, de-emphasised and notched; while the pilot PLL (processPilotPll, :390-430) reports lock at the end of a
+ * block of frames_per_buffer samples that block is demultiplexed (left - right = 2 raw sin(2 phase)), otherwise it carries the same
+ * signal in both channels.  The PLL's phase detector (:792-821) is discontinuous at the loop's operating point and the lock is lost
+ * within the first blocks on every input it has been tried on (pinned on the oracle's line-by-line restatement with clean, noisy,
+ * weak and absent pilots at the demodulator rates the receiver runs, tests/test_oracle_pins.py -- other inputs: parity unpinned);
+ * the library runs the loop, serially per channel, until the first block that ends without lock and treats the stream as mono from
+ * there (the lock average would need seconds of a quiet detector to come back).  Not reproduced: the RDS bit decoder (GUI text). */
 int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
 /* AGC::setAgcMode(mode, threshold) (application/agc.cpp:53-82; Receiver::agcModeChanged/agcThresholdChanged).
  * agc_mode: the reference's AgcMode values.  With PEBBLEGPU_AGC_OFF the threshold is a manual gain slider in dB

@@ -1308,6 +1308,7 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 {
     C = channels;
     rate = demod_rate;
+    max_n_ = max_n;
     stereo.assign(C, 0);
     lp_on = rate >= 150000;  // demod_wfm.cpp:210
     const design::Biquad l = design::biquad_lowpass(75000, 1.0, rate);   // demod_wfm.cpp:164
@@ -1365,8 +1366,12 @@ int WfmCore::init(uint32_t channels, double demod_rate, long long max_n)
 void WfmCore::release()
 {
     a.release(); b.release(); c.release();
-    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_h, d_hlp, d_xtail[0], d_xtail[1], d_stereo};
+    void *p[] = {d_taps, d_lp_state[0], d_lp_state[1], d_dn_state[0], d_dn_state[1], d_h, d_hlp, d_xtail[0], d_xtail[1], d_stereo, d_pilot, d_hilb, d_stereo_list};
     d_stereo = nullptr;
+    d_pilot = nullptr;
+    d_hilb = nullptr;
+    d_stereo_list = nullptr;
+    lm.release();
     for (void *q : p) if (q) (void)hipFree(q);
     d_taps = nullptr;
     d_lp_state[0] = d_lp_state[1] = d_dn_state[0] = d_dn_state[1] = nullptr;
@@ -1376,6 +1381,25 @@ int WfmCore::set_stereo(uint32_t ch, bool on)
 {
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
     if (on && !fused) return fail(PEBBLEGPU_E_UNSUPPORTED, "dmFMS needs the single-kernel WFM path (this demodulator rate runs the sequential one)");
+    if (on && !d_pilot) {  // first dmFMS channel of this object: the pilot loop's constants, state and the (L - R) rows
+        const design::WfmPilotDesign pd = design::wfm_pilot_design(rate);
+        memset(&pilot, 0, sizeof(pilot));
+        pilot.b0 = pd.bp.b0; pilot.b2 = pd.bp.b2; pilot.a1 = pd.bp.a1; pilot.a2 = pd.bp.a2;
+        pilot.nco_lo = pd.nco_lo; pilot.nco_hi = pd.nco_hi; pilot.alpha = pd.alpha; pilot.beta = pd.beta;
+        pilot.err_alpha = pd.err_alpha; pilot.phase_adjust = pd.phase_adjust;
+        pilot.L4 = L4;
+        PG_HIP(hipMalloc((void **)&d_hilb, sizeof(double) * 122));
+        PG_HIP(hipMemcpy(d_hilb, pd.hilb, sizeof(double) * 122, hipMemcpyHostToDevice));
+        PG_HIP(hipMalloc((void **)&d_pilot, sizeof(WfmPilotState) * C));
+        PG_HIP(hipMalloc((void **)&d_stereo_list, sizeof(int) * C));
+        if (int rc = lm.alloc((int)C, L4 + 16, max_n_)) return rc;
+        // initPilotPll (demod_wfm.cpp:371-386), once per object as in the reference: a channel that leaves dmFMS and comes back finds its
+        // loop where it left it (its lock average still high: it stays dropped)
+        std::vector<WfmPilotState> z(C);
+        memset(z.data(), 0, sizeof(WfmPilotState) * C);
+        for (auto &q : z) { q.nco_freq = pd.nco_freq0; q.quiet = 1LL << 40; }
+        PG_HIP(hipMemcpy(d_pilot, z.data(), sizeof(WfmPilotState) * C, hipMemcpyHostToDevice));
+    }
     if (stereo[ch] != (unsigned char)on) stereo_dirty = true;
     stereo[ch] = on;
     return 0;
@@ -1389,6 +1413,10 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
     if (stereo_dirty) {  // (rare: a mode change)
         if (!d_stereo) PG_HIP(hipMalloc((void **)&d_stereo, C));
         PG_HIP(hipMemcpyAsync(d_stereo, stereo.data(), C, hipMemcpyHostToDevice, s));
+        std::vector<int> list;
+        for (uint32_t ch = 0; ch < C; ch++) if (stereo[ch]) list.push_back((int)ch);
+        n_stereo = (int)list.size();
+        if (n_stereo) PG_HIP(hipMemcpyAsync(d_stereo_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, s));
         PG_HIP(hipStreamSynchronize(s));
         stereo_dirty = false;
     }
@@ -1431,6 +1459,20 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
             PG_HIP(hipMemcpy2DAsync(nt + (Lx - n), sizeof(float2) * Lx, in, sizeof(float2) * in_pitch, sizeof(float2) * n, C, hipMemcpyDeviceToDevice, s));
         }
         parity ^= 1;
+        if (n_stereo) {
+            // dmFMS before the pilot PLL's drop-out: the (L - R) part of the blocks that end locked, through the same audio response
+            if (n > lm.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
+            PG_HIP(hipMemset2DAsync(lm.data(), sizeof(float2) * (size_t)lm.pitch, 0, sizeof(float2) * (size_t)n, C, s));
+            WfmPilotParams pp = pilot;
+            pp.block = stereo_block > 0 ? stereo_block : (int)n;
+            launch(k_wfm_pilot, dim3(cdiv(n_stereo, 64)), dim3(64), s, in, in_pitch, n, pp, (const double *)d_hilb, d_pilot, lm.data(), lm.pitch,
+                   (const int *)d_stereo_list, n_stereo);
+            launch(k_wfm_lmr_fir, dim3(cdiv(n, 256), n_stereo), dim3(256), s, (const float2 *)lm.data(), lm.pitch, (const float *)d_h, L4, out, out_pitch, n,
+                   (const WfmPilotState *)d_pilot, (const int *)d_stereo_list);
+            std::vector<TailJob> lj(1, TailJob{lm.data(), lm.pitch, n, lm.hist, 0, nullptr, 0});
+            if (int rc = run_save_tails(s, lj, C)) return rc;
+            PG_HIP(hipGetLastError());
+        }
         return 0;
     }
     if (n > a.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);

@@ -172,6 +172,10 @@ static Biquad rbj(double f0, double q, double fs, int kind)
         b.b0 = A * ((1.0 - std::cos(w0)) / 2.0);
         b.b1 = A * (1.0 - std::cos(w0));
         b.b2 = b.b0;
+    } else if (kind == 3) {  // band-pass, iir.cpp:131-146
+        b.b0 = A * alpha;
+        b.b1 = 0.0;
+        b.b2 = A * -alpha;
     } else if (kind == 2) {  // high-pass, iir.cpp:110-125
         b.b0 = A * ((1.0 + std::cos(w0)) / 2.0);
         b.b1 = -A * (1.0 + std::cos(w0));
@@ -186,6 +190,39 @@ static Biquad rbj(double f0, double q, double fs, int kind)
 Biquad biquad_lowpass(double f0, double q, double fs) { return rbj(f0, q, fs, 0); }
 Biquad biquad_notch(double f0, double q, double fs) { return rbj(f0, q, fs, 1); }
 Biquad biquad_highpass(double f0, double q, double fs) { return rbj(f0, q, fs, 2); }
+Biquad biquad_bandpass(double f0, double q, double fs) { return rbj(f0, q, fs, 3); }
+
+// HILBLP_H, demod_wfm.cpp:79-98 (data): the 61-tap symmetric low-pass prototype the Hilbert pair is shifted from; first 31 taps
+static const double kHilbHalf[31] = {
+    -0.000389631665953405, 0.000115430826670992, 0.000945331102222503, 0.001582460677684605,
+    0.001370803713784687, -0.000000000000000002, -0.002077413537668161, -0.003656132107176520,
+    -0.003372610825000167, -0.000649815020884706, 0.003583263233560064, 0.006997162933343487,
+    0.006990985399916562, 0.002383133886438500, -0.005324501734543406, -0.012092135317628615,
+    -0.013212201698221963, -0.006168904735839018, 0.007082277142635906, 0.020017841466263672,
+    0.024271835962039127, 0.014255112728911837, -0.008597071392140753, -0.034478282954624850,
+    -0.048147195828726633, -0.035409729589347565, 0.009623663461671806, 0.080084441681677138,
+    0.157278883310078170, 0.217148915611638180, 0.239688166538436750
+};
+WfmPilotDesign wfm_pilot_design(double fs)
+{
+    WfmPilotDesign d;
+    for (int n = 0; n < 61; n++) {  // CFir::GenerateHBFilter(42000), fir.cpp:212-243: the prototype shifted up, I and Q taps
+        const double h = kHilbHalf[n <= 30 ? n : 60 - n];
+        const double a = (kTwoPi * 42000.0 / fs) * ((double)n - 30.0);
+        d.hilb[n] = 2.0 * h * std::cos(a);
+        d.hilb[61 + n] = 2.0 * h * std::sin(a);
+    }
+    d.bp = biquad_bandpass(19000.0, 500, fs);  // demod_wfm.cpp:171
+    const double norm = kTwoPi / fs;
+    d.nco_freq0 = -19000.0;                    // :374, as written: hertz until the loop's first clamp
+    d.nco_lo = (d.nco_freq0 - 20.0) * norm;    // PILOTPLL_RANGE
+    d.nco_hi = (d.nco_freq0 + 20.0) * norm;
+    d.alpha = 2.0 * .707 * 10.0 * norm;        // PILOTPLL_ZETA, PILOTPLL_BW
+    d.beta = (d.alpha * d.alpha) / (4.0 * .707 * .707);
+    d.err_alpha = 1.0 - std::exp(-1.0 / (fs * .5));  // LOCK_TIMECONST
+    d.phase_adjust = -7.267e-6 * fs + 3.677;   // PHASE_ADJ_M, PHASE_ADJ_B, :60-61, :161
+    return d;
+}
 
 double blackman_harris(uint32_t n, std::vector<double> &w)
 {

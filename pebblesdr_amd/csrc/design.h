@@ -58,6 +58,17 @@ struct Biquad { double b0, b1, b2, a1, a2; };
 Biquad biquad_lowpass(double f0, double q, double fs);
 Biquad biquad_notch(double f0, double q, double fs);
 Biquad biquad_highpass(double f0, double q, double fs);
+Biquad biquad_bandpass(double f0, double q, double fs);   // CIir::InitBP, iir.cpp:131-146
+
+// Demod_WFM's stereo members at demodulator rate fs (demod_wfm.cpp:161-171 setSampleRate, :371-386 initPilotPll): the 61-tap Hilbert
+// pair [I taps | Q taps] (InitConstFir(HILB_LENGTH, HILBLP_H) + GenerateHBFilter(42000), fir.cpp:176-243), the pilot band-pass and the
+// PLL's constants
+struct WfmPilotDesign {
+    double hilb[2 * 61];
+    Biquad bp;
+    double nco_lo, nco_hi, alpha, beta, err_alpha, phase_adjust, nco_freq0;
+};
+WfmPilotDesign wfm_pilot_design(double fs);
 
 // WindowFunction BLACKMANHARRIS, pebblelib/windowfunction.cpp:214-235; returns coherentGain = sum/N
 double blackman_harris(uint32_t n, std::vector<double> &w);

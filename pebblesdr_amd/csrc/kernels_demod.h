@@ -299,6 +299,129 @@ static __global__ __launch_bounds__(512) void k_wfm_fir(const float2 *__restrict
         }
 }
 
+// FM stereo while the reference's pilot PLL still reports lock (Demod_WFM::processDataStereo, demod_wfm.cpp:255-297; processPilotPll
+// :392-429; arctan2 :792-821): the discriminator, the 61-tap Hilbert pair, the pilot band-pass and the PLL are one serial loop per
+// channel -- nonlinear feedback -- in double as the reference declares it; one lane per channel.  The lock decision is taken at the
+// END of a block and applies to the whole block: a locked block contributes lmr[i] = 2 raw[i] sin(2 (nco_phase_i + adjust)) to
+// left - right, an unlocked one nothing.  The first block that ends without lock ends the loop for good (`dropped`): the lock
+// average, once above its threshold, needs seconds of a quiet phase detector to come back, and this detector never settles
+// (tests/test_oracle_pins.py::test_wfm_stereo_pilot_pll_of_the_reference_does_not_hold_lock) -- from there on dmFMS is what k_wfm_fir
+// delivers by itself.  lm: [channel][lm_pitch] float2 rows with the audio response's look-back as head-room, .x = lmr (zeroed by the
+// caller before the launch: only locked blocks are written).
+static __global__ __launch_bounds__(64) void k_wfm_pilot(const float2 *__restrict__ in, long long in_pitch, long long n, WfmPilotParams pp,
+                                                         const double *__restrict__ hilb, WfmPilotState *__restrict__ st,
+                                                         float2 *__restrict__ lm, long long lm_pitch, const int *__restrict__ chan_list, int nlist)
+{
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nlist) return;
+    const int c = chan_list[li];
+    WfmPilotState *s = &st[c];
+    const long long quiet0 = s->quiet;
+    if (s->dropped) {
+        s->skip = quiet0 >= (long long)pp.L4 ? 1 : 0;
+        const long long q = quiet0 + n;
+        s->quiet = q > (1LL << 40) ? (1LL << 40) : q;
+        const float2 v = in[(long long)c * in_pitch + n - 1];
+        s->d1_re = (double)v.x;
+        s->d1_im = (double)v.y;
+        return;
+    }
+    s->skip = 0;
+    const double kTwoPi = 6.28318530717958647692528676656, kPiD = 3.14159265358979323846;
+    const float2 *x = in + (long long)c * in_pitch;
+    float2 *l = lm + (long long)c * lm_pitch;
+    double d1r = s->d1_re, d1i = s->d1_im, w1a = s->w1a, w2a = s->w2a, w1b = s->w1b, w2b = s->w2b;
+    double nco_phase = s->nco_phase, nco_freq = s->nco_freq, err_ave = s->err_ave;
+    int zpos = s->zpos;
+    long long quiet = quiet0;
+    const double *hI = hilb, *hQ = hilb + 61;
+    for (long long b0 = 0; b0 < n; b0 += pp.block) {
+        const long long be = b0 + pp.block < n ? b0 + pp.block : n;
+        for (long long i = b0; i < be; i++) {
+            const double xr = (double)x[i].x, xi = (double)x[i].y;
+            const double raw = 0.25 * atan2(d1r * xi - xr * d1i, d1r * xr + d1i * xi);  // :258-263 (FMDEMOD_GAIN)
+            d1r = xr; d1i = xi;
+            // CFir::ProcessFilter, real in / complex out (fir.cpp:106-154): y = sum_k h[k] raw[i - k]
+            zpos = zpos == 0 ? 60 : zpos - 1;
+            s->z[zpos] = raw;
+            double hr = 0.0, hi = 0.0;
+            int q = zpos;
+            for (int k = 0; k < 61; k++) {
+                const double zv = s->z[q];
+                hr += hI[k] * zv;
+                hi += hQ[k] * zv;
+                q = q == 60 ? 0 : q + 1;
+            }
+            // pilot band-pass, direct form 2 (iir.cpp:191-207)
+            const double w0a = hr - pp.a1 * w1a - pp.a2 * w2a;
+            const double pr = pp.b0 * w0a + pp.b2 * w2a;
+            w2a = w1a; w1a = w0a;
+            const double w0b = hi - pp.a1 * w1b - pp.a2 * w2b;
+            const double pi = pp.b0 * w0b + pp.b2 * w2b;
+            w2b = w1b; w1b = w0b;
+            // processPilotPll, :392-429
+            const double sn = sin(nco_phase), cs = cos(nco_phase);
+            const double tr = cs * pr - sn * pi, ti = cs * pi + sn * pr;
+            double ang;  // Demod_WFM::arctan2(ti, tr), :792-821, with its constants as written
+            if (tr == 0.0) ang = ti > 0.0 ? kTwoPi : (ti == 0.0 ? 0.0 : -kTwoPi);
+            else {
+                const double zq = ti / tr;
+                if (fabs(zq) < 1.0) {
+                    ang = zq / (1.0 + 0.2854 * zq * zq);
+                    if (tr < 0.0) ang = ti < 0.0 ? ang - kPiD : ang + kPiD;
+                } else {
+                    ang = kTwoPi - zq / (zq * zq + 0.2854);
+                    if (ti < 0.0) ang -= kPiD;
+                }
+            }
+            const double err = -ang;
+            nco_freq += pp.beta * err;
+            if (nco_freq > pp.nco_hi) nco_freq = pp.nco_hi;
+            else if (nco_freq < pp.nco_lo) nco_freq = pp.nco_lo;
+            nco_phase += nco_freq + pp.alpha * err;
+            err_ave = (1.0 - pp.err_alpha) * err_ave + pp.err_alpha * err * err;
+            l[i].x = (float)(2.0 * raw * sin((nco_phase + pp.phase_adjust) * 2.0));  // kept if the block ends locked
+        }
+        nco_phase = fmod(nco_phase, kTwoPi);
+        if (!(err_ave < 0.05)) {  // LOCK_MAG_THRESHOLD: the block copies the mono signal
+            for (long long i = b0; i < be; i++) l[i].x = 0.f;
+            s->dropped = 1;
+            quiet += n - b0;
+            break;
+        }
+        quiet = 0;
+    }
+    s->d1_re = (double)x[n - 1].x; s->d1_im = (double)x[n - 1].y;
+    s->w1a = w1a; s->w2a = w2a; s->w1b = w1b; s->w2b = w2b;
+    s->nco_phase = nco_phase; s->nco_freq = nco_freq; s->err_ave = err_ave;
+    s->zpos = zpos;
+    s->quiet = quiet;
+}
+
+// out[c][i] += (w, -w), w = sum_p h[p] lmr[i - p]: the (L - R) part through the audio response k_wfm_fir applies to L + R
+// (demod_wfm.cpp:359-361 are linear: FIR, de-emphasis, notch).  grid (ceil(n / 256), listed channels).
+static __global__ __launch_bounds__(256) void k_wfm_lmr_fir(const float2 *__restrict__ lm, long long lm_pitch, const float *__restrict__ h, int L4,
+                                                           float2 *__restrict__ out, long long out_pitch, long long n,
+                                                           const WfmPilotState *__restrict__ st, const int *__restrict__ chan_list)
+{
+    const int c = chan_list[blockIdx.y];
+    if (st[c].skip) return;  // workgroup-uniform
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 *l = lm + (long long)c * lm_pitch + i;
+    double acc = 0.0;
+    for (int p0 = 0; p0 < L4; p0 += 16) {
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; u++) a = fmaf(h[p0 + u], l[-(p0 + u)].x, a);
+        acc += (double)a;
+    }
+    float2 *y = out + (long long)c * out_pitch + i;
+    const float w = (float)acc;
+    const float2 v = *y;
+    *y = make_float2(v.x + w, v.y - w);
+}
+
 // The PLL demodulators -- Demod_NFM::processBlockNCO (application/demod/demod_nfm.cpp:225-257) and Demod_SAM::pll /
 // processBlock (demod_sam.cpp:41-101) -- are NON-linear feedback loops: serial in time, parallel only across channels.
 // One lane per channel walks the call; the loop state is `float` exactly as the reference declares it

@@ -100,6 +100,26 @@ struct TailJobs {
     TailJob job[kMaxTailJobs];
 };
 
+// Demod_WFM::processDataStereo before its pilot PLL drops out (application/demod/demod_wfm.cpp:255-297, :392-429): the constants of one
+// demodulator rate and the state one channel carries.  hilb: [2][61] the 61-tap Hilbert pair (I taps, Q taps) in device memory.
+struct WfmPilotParams {
+    double b0, b2, a1, a2;                 // pilot band-pass biquad (b1 = 0), iir.cpp:131-146
+    double nco_lo, nco_hi, alpha, beta;    // initPilotPll, :371-386
+    double err_alpha, phase_adjust;
+    int block;                             // samples per processDataStereo call (the lock decision is per block)
+    int L4;                                // length of the audio response the (L - R) part will go through
+};
+struct WfmPilotState {
+    double d1_re, d1_im;                   // the discriminator's previous sample
+    double z[61];                          // the Hilbert filter's delay line (discriminator values), circular
+    double w1a, w2a, w1b, w2b;             // pilot band-pass
+    double nco_phase, nco_freq, err_ave;
+    int zpos;
+    int dropped;                           // a block has ended without lock: from here on the block copies the mono signal (see WfmCore)
+    long long quiet;                       // (L - R) samples that have been zero at the end of the stream so far, saturating
+    int skip, pad_;                        // this call adds nothing to the output (set per call for the FIR behind)
+};
+
 // A stream still in the device's own sample format (DeviceInterfaceBase::normalizeIQ, pebblelib/deviceinterfacebase.cpp:648-838, done
 // in the first loads of the kernels that take it instead of a separate pass): base == nullptr: the float2 pointer is the input.
 //   fmt 0 CPX8 int8 pairs, 1 CPXU8 (v - 128), 2 CPX16, 3 CPXFLOAT, 4 WAV PCM16; order 0 IQ, 1 QI, 2 I only, 3 Q only; scale includes the gain

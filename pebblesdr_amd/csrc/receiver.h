@@ -264,6 +264,17 @@ struct WfmCore {
     unsigned char *d_stereo = nullptr;        // device copy, uploaded by run() when dirty; null until a channel asks for it
     bool stereo_dirty = false;
     int set_stereo(uint32_t ch, bool on);
+    // ... and before it drops out (at most the first blocks of a stream): k_wfm_pilot runs the discriminator, the Hilbert pair, the
+    // pilot band-pass and the PLL serially per dmFMS channel and leaves the (L - R) contribution of the blocks that end locked in `lm`;
+    // k_wfm_lmr_fir sends it through the audio response and adds / subtracts it.  Allocated when a channel first asks for dmFMS.
+    HistBuf lm;                               // [C] rows, .x = lmr, head-room = the audio response's look-back
+    struct WfmPilotState *d_pilot = nullptr;  // [C]
+    double *d_hilb = nullptr;                 // [2][61]
+    int *d_stereo_list = nullptr;             // the dmFMS channels
+    int n_stereo = 0;
+    long long max_n_ = 0;
+    int stereo_block = 2048;                  // samples per processDataStereo call in the reference (the owner's frame length)
+    WfmPilotParams pilot;
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     // more_tails / oa: the caller's other tail-refresh jobs and oscillator advance; when the single-kernel path runs it carries

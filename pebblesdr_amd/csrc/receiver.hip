@@ -78,6 +78,7 @@ int Receiver::create(const pebblegpu_config *cfg)
         if (int rc = anf_.init(C)) return rc;
     } else {
         if (int rc = wfmc_.init(C, (double)demod_rate_int, nd_max)) return rc;  // Demod_WFM(m_inputWfmSampleRate), demod.cpp:65
+        wfmc_.stereo_block = (int)nf;  // the reference demodulates one accumulated frame per call (receiver.cpp:896)
     }
     if (int rc = cond_.init(S, nf, fs, max_n)) return rc;
     audio_rate = cfg->audio_rate;

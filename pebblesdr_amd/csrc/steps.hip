@@ -471,6 +471,7 @@ int pebblegpu_demod_create(int device, uint32_t sample_rate, uint32_t wfm_sample
         if (!rc) rc = d->nfm.set_list(d->stream, std::vector<int>(1, 0));
     }
     if (!rc && wfm_sample_rate) rc = d->wfm.init(1, (double)wfm_sample_rate, buffer_size);
+    d->wfm.stereo_block = 0;  // a processBlock call is one block
     if (!rc && hipMalloc((void **)&d->d_in, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
     if (!rc && hipMalloc((void **)&d->d_out, sizeof(float2) * buffer_size) != hipSuccess) rc = fail(PEBBLEGPU_E_HIP, "hipMalloc failed");
     if (rc) { pebblegpu_demod_destroy(d); return rc; }

@@ -232,17 +232,21 @@ def _fm_stereo_mpx(fs, n_samples, pilot_phase=1.0):
 
 
 @pytest.mark.parametrize("fsw", [256000, 312500])
-def test_wfm_stereo_mode_is_the_reference_after_its_pilot_pll_drops_out(gpu_lib, oracle_mod, fsw):
-    """dmFMS (include/pebblegpu.h at pebblegpu_set_demod_mode): processDataStereo restated line by line in the oracle loses
-    pilot lock within its first three blocks and from then on delivers the discriminator output, without processDataMono's
-    75 kHz pre-filter, in both channels.  The device path is compared with exactly those blocks; switching FMS -> FMM -> FMS
-    on a running stream follows the oracle too, except for the switch transient: the reference carries the discriminator's last
-    sample and the mono pre-filter's state across the switch (one filtered, one not; the pre-filter asleep during the stereo
-    blocks), the device reads the true input history -- a one-sample difference that rings through the audio filters' ~700-tap
-    response, so the first block after a switch is compared behind it."""
+@pytest.mark.parametrize("pilot_phase", [1.0, 2.5])
+def test_wfm_stereo_mode_is_the_reference_from_the_first_block(gpu_lib, oracle_mod, fsw, pilot_phase):
+    """dmFMS (include/pebblegpu.h at pebblegpu_set_demod_mode): processDataStereo restated line by line in the oracle.  Its pilot
+    PLL loses lock within the first three blocks and from then on the block delivers the discriminator output, without
+    processDataMono's 75 kHz pre-filter, in both channels; a block that ENDS with the lock average under its threshold (pilot phase
+    1.0: the first two) is demultiplexed -- left - right = 2 raw sin(2 phase) through the same audio filters.  The device runs that
+    loop serially per channel until the first block without lock (k_wfm_pilot) and adds the (L - R) part (k_wfm_lmr_fir): every
+    block from the first at 1e-5, both channels.  Switching FMS -> FMM -> FMS on a running stream follows the oracle too (the loop's
+    state stays as it was: the channel remains dropped), except for the switch transient: the reference carries the discriminator's
+    last sample and the mono pre-filter's state across the switch (one filtered, one not), the device reads the true input history
+    -- a one-sample difference that rings through the audio filters' ~700-tap response, so the first block after a switch is
+    compared behind it."""
     import pebblesdr_amd as P
     n, blocks = 2048, 16
-    x = _fm_stereo_mpx(fsw, n * blocks) + lcg_noise(n * blocks, 9, 1e-4)
+    x = _fm_stereo_mpx(fsw, n * blocks, pilot_phase) + lcg_noise(n * blocks, 9, 1e-4)
     ref = oracle_mod.DemodWFM(fsw)
     d = P.Demod(64000, fsw, 4 * n)
     d.setDemodMode(P.DM_FMS)
@@ -252,10 +256,14 @@ def test_wfm_stereo_mode_is_the_reference_after_its_pilot_pll_drops_out(gpu_lib,
         r, lk = ref.process_stereo(fr)
         g = d.processBlock(fr)
         locks.append(lk)
-        assert np.array_equal(g.real, g.imag)  # one signal in both channels
-        if k >= 3:
-            assert not lk and rel_rms(g, r) <= TOL
+        assert rel_rms(g.real, r.real) <= TOL and rel_rms(g.imag, r.imag) <= TOL, (k, locks)
+        if lk:
+            assert not np.array_equal(r.real, r.imag)  # a demultiplexed block: the channels differ
+        if k >= 4:
+            assert np.array_equal(g.real, g.imag)      # one signal in both channels once the (L - R) part has rung out
     assert not any(locks[3:])
+    if pilot_phase == 1.0 and fsw == 312500:
+        assert locks[0] and locks[1]                    # this case exercises the demultiplexed blocks
     d.setDemodMode(P.DM_FMM)
     for k in range(10, 13):
         fr = x[k * n:(k + 1) * n]
@@ -272,8 +280,8 @@ def test_wfm_stereo_mode_is_the_reference_after_its_pilot_pll_drops_out(gpu_lib,
 
 
 def test_wfm_stereo_mode_in_the_receiver(gpu_lib, oracle_mod):
-    """The same through the whole chain: a 2.5 Msps WFM receiver in dmFMS against the oracle's Receiver in the same mode, from
-    the super-frame in which the oracle's pilot PLL has dropped out."""
+    """The same through the whole chain: a 2.5 Msps WFM receiver in dmFMS against the oracle's Receiver in the same mode, every
+    super-frame from the first, the first two in one call."""
     import pebblesdr_amd as P
     fs, n = 2_500_000, 2048
     rx = P.ReceiverBank(fs, 1, True, True, 0, max_superframes=2)
@@ -291,11 +299,14 @@ def test_wfm_stereo_mode_in_the_receiver(gpu_lib, oracle_mod):
         a, _ = ref.process(x[f * n:(f + 1) * n], want_spectrum=False)
         if len(a):
             ra.append(a)
-    ga = [rx.process(x[k * sf:(k + 1) * sf])[0][0] for k in range(K)]
+    first = rx.process(x[:2 * sf])[0][0]  # two demodulator blocks in one call: the lock decision is per block of frames_per_buffer samples
+    ga = [first[:n], first[n:]] + [rx.process(x[k * sf:(k + 1) * sf])[0][0] for k in range(2, K)]
     assert len(ra) == K
+    assert not np.array_equal(ra[0].real, ra[0].imag)  # the oracle demultiplexes the first block of this stream (pilot phase 1.0)
+    for k in range(K):  # from the first super-frame on: the blocks before the pilot PLL's drop-out included
+        assert rel_rms(ga[k].real, ra[k].real) <= TOL and rel_rms(ga[k].imag, ra[k].imag) <= TOL, k
     for k in range(4, K):
         assert np.array_equal(ga[k].real, ga[k].imag)
-        assert rel_rms(ga[k], ra[k]) <= TOL
 
 
 def test_wfm_bank_with_mono_and_stereo_channels(gpu_lib, oracle_mod):
