@@ -1137,7 +1137,8 @@ int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, fl
     const dim3 grid((unsigned)(n / L), C), block(256);
     const float2 *tail = d_tail;
     if (fft_n == 2048) {
-        launch(k_fastfir_t128, grid, dim3(128), s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
+        static const size_t pad = [] { const char *e = getenv("PEBBLEGPU_FF_PADLDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // A/B: extra LDS per workgroup (lowers its occupancy)
+        launch_lds(k_fastfir_t128, grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
         if (d_tail_next) {  // the kernel's last block has written the next call's overlap into the caller's other buffer
             PG_HIP(hipGetLastError());
             return 0;

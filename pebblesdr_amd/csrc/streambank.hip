@@ -7,6 +7,8 @@ using pg::fail;
 struct pebblegpu_streambank {
     pebblegpu_streambank_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // the band-pass of a call that also asks for the spectrum runs here, beside the transform
+    bool side_ok = true, side = false;
     pg::FastFirCore ff;
     pg::SpectrumCore sp;
     float2 *d_tail = nullptr, *d_tail_alt = nullptr, *d_filt = nullptr;  // (the two overlap buffers swap after every band-pass call)
@@ -22,6 +24,10 @@ int pebblegpu_streambank_destroy(pebblegpu_streambank *sb)
 {
     if (!sb) return 0;
     (void)hipSetDevice(sb->cfg.device);
+    if (sb->stream2) {
+        (void)hipStreamSynchronize(sb->stream2);
+        (void)hipStreamDestroy(sb->stream2);
+    }
     if (sb->stream) {
         (void)hipStreamSynchronize(sb->stream);
         (void)hipStreamDestroy(sb->stream);
@@ -54,6 +60,8 @@ int pebblegpu_streambank_create(const pebblegpu_streambank_config *cfg, pebblegp
     auto body = [&]() -> int {
         PG_HIP(hipSetDevice(cfg->device));
         PG_HIP(hipStreamCreateWithFlags(&sb->stream, hipStreamNonBlocking));
+        PG_HIP(hipStreamCreateWithFlags(&sb->stream2, hipStreamNonBlocking));
+        { const char *e = getenv("PEBBLEGPU_SB_SIDE"); sb->side_ok = e && e[0] == '1'; }  // opt-in: measured equal (below)
         if (int r = sb->ff.init(S, sb->cfg.fastfir_fft, sb->cfg.fastfir_taps)) return r;
         if (int r = sb->sp.init(S, cfg->frame, cfg->spectrum_bins)) return r;
         if (cfg->frame % (uint64_t)sb->ff.block_len()) return fail(PEBBLEGPU_E_SIZE, "frame %u is not a multiple of the band-pass block %lld", cfg->frame, sb->ff.block_len());
@@ -96,17 +104,31 @@ int pebblegpu_streambank_process(pebblegpu_streambank *sb, const void *d_iq, uin
     sb->last_frames = 0;
     if (n == 0) return 0;
     PG_HIP(hipEventRecord(sb->ev[0], sb->stream));
+    // Both asked for: the band-pass (bound by its two transforms per block: vector units + LDS) and the display transform (the 65536-point
+    // one is bound by what it moves through HBM) read the same input and share nothing else.  Side by side on two streams (fork at the
+    // call's start event, join at its end; PEBBLEGPU_SB_SIDE=1 when the bank is created) they do NOT overlap: 0.4345 / 0.4368 ms per
+    // configs[4] call against 0.4346 / 0.4422 one after the other -- the band-pass's 32768 small workgroups fill every CU's LDS first and the
+    // transform's workgroups wait for them; with the band-pass's occupancy cut (8 / 16 / 30 kB of extra LDS per workgroup) both get slower
+    // (0.46 / 0.48 / 0.52).  Opt-in, not the default.
+    const bool side = sb->side_ok && (what & 3u) == 3u;
+    sb->side = side;
+    hipStream_t fs = side ? sb->stream2 : sb->stream;
+    if (side) PG_HIP(hipStreamWaitEvent(fs, sb->ev[0], 0));
     if (what & 1u) {
         float2 *next = sb->ff.fft_n == 2048 ? sb->d_tail_alt : nullptr;
-        if (int rc = sb->ff.run_ext(sb->stream, in, (long long)n, sb->d_tail, (long long)n, sb->d_filt, (long long)n, next)) return rc;
+        if (int rc = sb->ff.run_ext(fs, in, (long long)n, sb->d_tail, (long long)n, sb->d_filt, (long long)n, next)) return rc;
         if (next) std::swap(sb->d_tail, sb->d_tail_alt);
         sb->last_n = n;
     }
-    PG_HIP(hipEventRecord(sb->ev[1], sb->stream));
+    PG_HIP(hipEventRecord(sb->ev[1], fs));
     if (what & 2u) {
         const long long F = (long long)(n / sb->cfg.frame);
-        if (int rc = sb->sp.run(sb->stream, in, (long long)n, F, sb->d_spec, nullptr, nullptr, true)) return rc;  // (one stream: nothing runs beside the transform)
+        if (int rc = sb->sp.run(sb->stream, in, (long long)n, F, sb->d_spec, nullptr, nullptr, !side)) return rc;
         sb->last_frames = (uint64_t)F;
+    }
+    if (side) {
+        PG_HIP(hipEventRecord(sb->ev[3], sb->stream));       // where the transform ended
+        PG_HIP(hipStreamWaitEvent(sb->stream, sb->ev[1], 0));  // join
     }
     PG_HIP(hipEventRecord(sb->ev[2], sb->stream));
     sb->timed = true;
@@ -134,7 +156,8 @@ int pebblegpu_streambank_last_ms(const pebblegpu_streambank *sb, int which, floa
     if (which < 0 || which > 2) return fail(PEBBLEGPU_E_INVALID, "which must be 0..2");
     PG_HIP(hipSetDevice(sb->cfg.device));
     PG_HIP(hipEventSynchronize(sb->ev[2]));
-    const int a = which == 2 ? 1 : 0, b = which == 1 ? 1 : 2;
+    // side by side both groups start at the call's start event; the transform's own end is ev[3]
+    const int a = (which == 2 && !sb->side) ? 1 : 0, b = which == 1 ? 1 : (which == 2 && sb->side ? 3 : 2);
     PG_HIP(hipEventElapsedTime(ms, sb->ev[a], sb->ev[b]));
     return 0;
 }
@@ -143,6 +166,7 @@ int pebblegpu_streambank_synchronize(pebblegpu_streambank *sb)
     if (!sb) return fail(PEBBLEGPU_E_INVALID, "null argument");
     PG_HIP(hipSetDevice(sb->cfg.device));
     PG_HIP(hipStreamSynchronize(sb->stream));
+    PG_HIP(hipStreamSynchronize(sb->stream2));
     return 0;
 }
 
