@@ -1121,7 +1121,11 @@ int FastFirCore::run(hipStream_t s, const HistBuf &in, long long n, float2 *out,
     if (n % L != 0) return fail(PEBBLEGPU_E_SIZE, "FastFIR input %lld is not a multiple of its block %lld", n, L);
     const dim3 grid((unsigned)(n / L), C), block(256);
     const float2 *no_tail = nullptr;
-    if (fft_n == 2048) launch(k_fastfir_t128, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr);
+    // (twiddles from the workgroup's LDS copy here: beside a bank's decimator -- two-stage calls -- the variant that reads them through the
+    // vector cache measured 0.0833 ms per configs[2] call against 0.0820; alone, in the stream bank, it is the faster one: run_ext)
+    static const bool tw_lds = [] { const char *e = getenv("PEBBLEGPU_FF_TWLDS"); return !(e && e[0] == '0'); }();
+    if (fft_n == 2048 && !tw_lds) launch(k_fastfir_t128<false>, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr);
+    else if (fft_n == 2048) launch(k_fastfir_t128<true>, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr);
     else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     else launch(k_fastfir<8192>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     PG_HIP(hipGetLastError());
@@ -1138,7 +1142,11 @@ int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, fl
     const float2 *tail = d_tail;
     if (fft_n == 2048) {
         static const size_t pad = [] { const char *e = getenv("PEBBLEGPU_FF_PADLDS"); return e ? (size_t)atol(e) : (size_t)0; }();  // A/B: extra LDS per workgroup (lowers its occupancy)
-        launch_lds(k_fastfir_t128, grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
+        // twiddles through the vector cache: without the 4.5 KB copy per workgroup eight workgroups fit a CU's LDS instead of six -- configs[4]'s
+        // band-pass 0.222 / 0.227 -> 0.215 / 0.211 ms in alternating runs (PEBBLEGPU_FF_TWLDS=1 brings the copy back)
+        static const bool twg = [] { const char *e = getenv("PEBBLEGPU_FF_TWLDS"); return !(e && e[0] == '1'); }();
+        if (twg) launch_lds(k_fastfir_t128<false>, grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
+        else launch_lds(k_fastfir_t128<true>, grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
         if (d_tail_next) {  // the kernel's last block has written the next call's overlap into the caller's other buffer
             PG_HIP(hipGetLastError());
             return 0;

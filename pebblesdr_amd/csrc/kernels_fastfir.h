@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void k_fastfir(const float2 *__restrict__ in, 
 // The 2048/1025 case (the reference's stock sizes) on the two-wave transform: a 128-item workgroup per block, 16 points
 // per work-item, barriers that only involve its own two waves.  The inverse transform is the forward one between two
 // conjugations.  grid (n / L, channels), block 128.
+template <bool TWLDS = true>
 static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__restrict__ in, long long in_pitch,
                                                              float2 *__restrict__ out, long long out_pitch,
                                                              const float2 *__restrict__ H, const float2 *__restrict__ tw128,
@@ -65,13 +66,14 @@ static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__res
 {
     constexpr int N = 2048, E = 16;
     __shared__ float2 lds[FftLds<N>::kSlots];
-    __shared__ float2 tw_lds[kTw128Count];
+    __shared__ float2 tw_lds_[TWLDS ? kTw128Count : 1];
+    const float2 *tw_lds = TWLDS ? tw_lds_ : tw128;  // (A/B: the twiddle table read through the vector cache instead of a copy per workgroup)
     const int t = threadIdx.x, c = blockIdx.y;
     const int L = N - overlap;
     const long long b = blockIdx.x;
     const float2 *x = in + (long long)c * in_pitch + b * L - overlap;  // first sample of [overlap | new]
     const float2 *h = H + (long long)c * N;
-    for (int i = t; i < kTw128Count; i += 128) tw_lds[i] = tw128[i];
+    if (TWLDS) for (int i = t; i < kTw128Count; i += 128) tw_lds_[i] = tw128[i];
     float2 v[E];
     if (tail != nullptr && b == 0) {
         const float2 *tl = tail + (long long)c * overlap;
