@@ -486,7 +486,9 @@ private:
     bool touched_ = true;             // a setter ran since the last call
     bool bank_pipe_ok_ = false;       // no display transform: the call's two stages (decimator | band-pass .. resampler) on the two streams, stage 2 beside the next call's stage 1
     hipEvent_t f_end_[2] = {nullptr, nullptr};  // where stage 2 of the last and of the last-but-one such call ended
-    hipEvent_t d_end_prev_ = nullptr;           // where stage 1 of the last call ended, if that was a two-stage call (the next one starts there)
+    hipEvent_t d_end_prev_ = nullptr;           // where the last call ended, if that was a two-stage call (the next one is timed from there)
+    hipEvent_t sync_ev_[4] = {nullptr, nullptr, nullptr, nullptr};  // stage 1 -> stage 2 hand-over events (no timing), a ring
+    hipEvent_t pipe_ev_ = nullptr;
     bool fuse_dec_ = false;           // the one-channel decimator inside the display transform's kernel (PEBBLEGPU_FUSE_DEC=1 at creation)
     hipEvent_t chain_end_ = nullptr;  // set when a two-stream call failed half-way: what was queued on the chain stream, for the main stream to wait on
     std::vector<ChanCtl> ctl_;

@@ -115,6 +115,7 @@ Receiver::~Receiver()
     if (stream_) (void)hipStreamSynchronize(stream_);
     osc_.release(); dec_.release(); ff_.release(); am_.release(); nfm_.release(); sam_.release(); wfmc_.release(); spec_.release(); zoom_.release();
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+    for (hipEvent_t e : sync_ev_) if (e) (void)hipEventDestroy(e);
     for (IngestSlot &g : ingest_) {
         if (g.h) (void)hipHostFree(g.h);
         if (g.d) (void)hipFree(g.d);
@@ -409,7 +410,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     // records no end event: it ends where the next call's start event is recorded (same queue, nothing in between), or where
     // sync() / a timing query closes it (close_timing).
     hipEvent_t start = ev[0];
-    if (bank_pipe && plain && d_end_prev_) start = d_end_prev_;  // (a two-stage call begins where the previous one's first stage ended: one queue packet less)
+    if (bank_pipe && plain && d_end_prev_) start = d_end_prev_;  // (back to back, a two-stage call is timed from where the previous one ended: one queue packet less)
     else PG_HIP(hipEventRecord(ev[0], stream_));
     tm.start_ev[slot] = start;
     if (tm.open_slot >= 0) {
@@ -486,9 +487,13 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         std::vector<TailJob> jobs;
         dec_.tail_jobs_dec(jobs);
         if (int rc = run_save_tails(stream_, jobs, C, &oa_pre)) return rc;  // (no launch at all behind the bank kernel: nothing left to do)
-        PG_HIP(hipEventRecord(ev[1], stream_));
+        // (an event without timing for the hand-over: PEBBLEGPU_BANK_PIPE_TIMED_EV=1 records the call's timing event instead -- A/B)
+        static const bool timed_ev = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_TIMED_EV"); return e && e[0] == '1'; }();
+        if (!sync_ev_[0]) for (hipEvent_t &e : sync_ev_) PG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pipe_ev_ = timed_ev ? ev[1] : sync_ev_[tm.calls % 4];
+        PG_HIP(hipEventRecord(pipe_ev_, stream_));
         cs = chain_stream_;
-        PG_HIP(hipStreamWaitEvent(cs, ev[1], 0));
+        PG_HIP(hipStreamWaitEvent(cs, pipe_ev_, 0));
         // (the next call's decimator becomes ready with the same event: a short nap lets its one-wave-per-SIMD workgroups be placed before
         // the band-pass fills the CUs -- placed behind them it ran 112 us instead of 65)
         static const unsigned nap = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_NAP_US"); return (unsigned)(100.0 * (e ? atof(e) : 8.0)); }();
@@ -588,10 +593,10 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (bank_pipe) {
         PG_HIP(hipEventRecord(ev[6], cs));
         chain_end_ = ev[6];   // for whoever needs both stages over: sync(), a call after a setter, a call of another shape
-        spec_end_ = ev[1];
+        spec_end_ = pipe_ev_;
         f_end_[1] = f_end_[0];
         f_end_[0] = ev[6];
-        d_end_prev_ = ev[1];
+        d_end_prev_ = ev[6];
     } else if (side && pipeline_) {
         // the call's two pipelines end separately: whoever needs both waits for both (sync(), the next call that is not plain)
         PG_HIP(hipEventRecord(ev[6], cs));
