@@ -440,7 +440,7 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
     while (2 * L <= warm) L *= 2;  // (only the first two chunks may reach in front of the call's start)
     const int S0 = first.stride, Sfs = cic ? S0 * wide_stride : S0;  // input samples per first-stage (hb11) output
     const long long pairs = cdiv(cdiv(len_out, L), 2);
-    const int hist_split = 4;
+    static const int hist_split = [] { const char *e = getenv("PEBBLEGPU_BANK_HSPLIT"); return e ? atoi(e) : 4; }();
     const unsigned n_wg = (unsigned)(8 * cdiv(pairs, 8) * cdiv(g32, 4) + cdiv(g32, 4) * hist_split);  // main workgroups, then the history waves'
     static unsigned long long *d_clk = nullptr;  // diagnosis only: PEBBLEGPU_BANK_CLK=1 prints the waves' clock counts of every such launch
     static size_t clk_cap = 0;
@@ -547,6 +547,14 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
             size_t over = 0;
             for (double v : per) over += v > 1.25 * per[per.size() / 2];
             fprintf(stderr, "\n   waves more than 25 %% over the median: %zu\n", over);
+            fprintf(stderr, "   workgroups with a wave more than 8 %% over the median:");
+            size_t last = (size_t)-1;
+            for (size_t w = 0; w < (size_t)n_wg * 4; w++)
+                if (h[4 * w + 2] && (double)h[4 * w] / (double)h[4 * w + 2] > 1.08 * per[per.size() / 2] && w / 4 != last) {
+                    fprintf(stderr, " %zu", w / 4);
+                    last = w / 4;
+                }
+            fprintf(stderr, "\n");
         }
     }
     hist_parity ^= 1;

@@ -82,7 +82,7 @@ struct BankDecParams {
 // pair; pairs = ceil(n_chunks / 2)), then ceil(n_groups / 4) workgroups of history waves.  (Single-wave workgroups were measured
 // first: the dispatcher put all four of a CU on one SIMD -- 1900 clocks per block instead of 1250; the four waves of one workgroup
 // go to the four SIMDs.)
-template <int NP, int T1, int T2, int T3, int DBG = 0, int MINW = 2>
+template <int NP, int T1, int T2, int T3, int DBG = 0, int MINW = 2, int EARLY = (NP == 4 ? 1 : 0)>
 static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, const ChanOsc *__restrict__ osc,
                                                                OscDynInline dyn, const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
                                                                const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,
@@ -92,14 +92,18 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     constexpr int H1 = (T1 + 1) / 2, H2 = (T2 + 1) / 2, H3 = (T3 + 1) / 2;
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY, WARM = G::warm;
     constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
+    constexpr bool kEarlyStore = EARLY != 0;  // where a block's store is issued (see the block's code)
     __shared__ float2 tiles[4][2][16 * 65];
-    __builtin_amdgcn_s_setprio(3);  // in front of the previous call's band-pass waves beside it (two-stage calls): this kernel is the call's length
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pairs = (P.n_chunks + 1) >> 1;
     const int gq = (P.n_groups + 3) >> 2;
     const int n_main = 8 * ((pairs + 7) >> 3) * gq;
     const bool hist_wave = (int)blockIdx.x >= n_main;  // (uniform)
+    // The main waves are the launch's length: they issue in front of whatever shares their SIMD -- the previous call's band-pass (two-stage
+    // calls) and this launch's own history waves (the main waves that had one of those beside them ran 1418 clocks per block against 1172
+    // and ended the kernel 8 us after the rest)
+    if (!hist_wave) __builtin_amdgcn_s_setprio(3);
     const int wq = blockIdx.x >> 3;
     const int hq = hist_wave ? (int)blockIdx.x - n_main : 0;  // history workgroups: [channel-group quad][part]
     const int hpart = hq % P.hist_split;
@@ -409,15 +413,18 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         row_run = st_row;
     };
     // the block's result into the tile being filled; one sixteenth of the other tile to memory
-    auto park_and_store = [&](float2 y, float2 sv) {
+    auto park = [&](float2 y) {
         *lds_at(twr) = v2f_t{y.x, y.y};
         twr += 8u * 65u;
+    };
+    auto store_sixteenth = [&](float2 sv) {
         unsigned vo = vo_cur;
         if (ragged) {
             vo = row_run < ch_lim ? vo : kNoStore;
             row_run += 2;
         }
-        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, (int)so_run, 0);
+        // (the scalar offset IS uniform; said so explicitly, or the compiler wraps the store in a loop over the lanes' values)
+        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, __builtin_amdgcn_readfirstlane((int)so_run), 0);
         so_run += so_row2;
     };
 
@@ -433,6 +440,13 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         // the oscillator at the centre of output j0's window: exact at every round's start, a constant rotation in between
         if ((rel & 15) == 0) round_start(rel, j0);
         else pa_blk = cmul2(r8, pa_blk);
+        // the tile read of this block's store: first thing, the store follows the sample requests below
+        float2 sv = make_float2(0.f, 0.f);
+        if constexpr ((DBG & 8) == 0 || EDGE) {
+            const v2f_t t = *lds_at(trd);
+            sv = make_float2(t.x, t.y);
+            trd += 16u;
+        }
         v2f_t pa[8];
         float2 y0[8];
         if constexpr ((DBG & 16) != 0 && !EDGE) {  // (timing experiment: no oscillator, no product)
@@ -453,6 +467,12 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         for (int p = 0; p < NP; p++) av[p] = __builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]);
         fetch_all(it + 2, edgec);
         voff += 64u * S;
+        // The block's store goes out right BEHIND those requests, not at the block's end: loads and stores retire through ONE in-order
+        // counter, so the wait for a block's samples is also a wait for every store issued in front of their requests.  At the block's
+        // end the store sat one block-time in front of the wait it blocks and cost 440 of the block's 1540 clocks (with either the
+        // fetches or the stores switched off the block took 1100); here it is younger than the requests the next wait is for and has
+        // two block-times to land.  (Its data is a sixteenth of the OTHER tile: it does not depend on this block's arithmetic.)
+        if constexpr (((DBG & 8) == 0 || EDGE) && kEarlyStore) store_sixteenth(sv);
         v16f_t acc = zero16;
         // Eight places between the stages take the block's NP matrix instructions, ceil-spread (NP = 4: places 0 2 4 6; NP = 12: two,
         // one, two, one ...); `after` ties the first one of a place to what the stage in front of it wrote
@@ -485,13 +505,6 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
             y0[7] = h7 ? yq[7] : y0[7];
 #pragma unroll
             for (int k = 0; k < 8; k++) yq[k] = yh[j0 + 8 + k];  // (the next block's)
-        }
-        // the tile read of this block's store goes first, the store last
-        float2 sv = make_float2(0.f, 0.f);
-        if constexpr ((DBG & 8) == 0 || EDGE) {
-            const v2f_t t = *lds_at(trd);
-            sv = make_float2(t.x, t.y);
-            trd += 16u;
         }
         // halfband 1 (transposed form, kernels_fused_dec.h): outputs 0..3 then 4..7 of the block
         float2 y1[4];
@@ -582,7 +595,8 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
 #pragma unroll
         for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
         if constexpr ((DBG & 8) == 0 || EDGE) {
-            park_and_store(cscale(y3, P.gain), sv);  // (the warm-up blocks' values land in rows that are rewritten before their tile is stored)
+            park(cscale(y3, P.gain));  // (the warm-up blocks' values land in rows that are rewritten before their tile is stored)
+            if constexpr (!kEarlyStore) store_sixteenth(sv);
         } else {
             asm volatile("" :: "v"(y3.x), "v"(y3.y));  // (timing experiment: no tile, no store)
         }
