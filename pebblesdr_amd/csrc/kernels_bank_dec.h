@@ -472,7 +472,8 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         // end the store sat one block-time in front of the wait it blocks and cost 440 of the block's 1540 clocks (with either the
         // fetches or the stores switched off the block took 1100); here it is younger than the requests the next wait is for and has
         // two block-times to land.  (Its data is a sixteenth of the OTHER tile: it does not depend on this block's arithmetic.)
-        if constexpr (((DBG & 8) == 0 || EDGE) && kEarlyStore) store_sixteenth(sv);
+        // (not in the edge blocks: behind their branching fetch the compiler drains every request in front of the store -- there it stays at the end)
+        if constexpr ((DBG & 8) == 0 && kEarlyStore && !EDGE) store_sixteenth(sv);
         v16f_t acc = zero16;
         // Eight places between the stages take the block's NP matrix instructions, ceil-spread (NP = 4: places 0 2 4 6; NP = 12: two,
         // one, two, one ...); `after` ties the first one of a place to what the stage in front of it wrote
@@ -596,7 +597,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         for (int i = 0; i + 1 < N3; i++) a3[i] = a3[i + 1];
         if constexpr ((DBG & 8) == 0 || EDGE) {
             park(cscale(y3, P.gain));  // (the warm-up blocks' values land in rows that are rewritten before their tile is stored)
-            if constexpr (!kEarlyStore) store_sixteenth(sv);
+            if constexpr (!kEarlyStore || EDGE) store_sixteenth(sv);
         } else {
             asm volatile("" :: "v"(y3.x), "v"(y3.y));  // (timing experiment: no tile, no store)
         }
