@@ -604,6 +604,11 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     };
 
     pa_blk = osc_exact(8 * (o0 - WARM - 1) - 7);  // (the block's in front of block 0: every block but a round's first opens with one rotation)
+    // A store that is dropped (out-of-range offset), so that the loops are ENTERED as they are re-entered: with a store behind the sample
+    // requests in flight.  The compiler merges the two states at a loop's head and waits for the worse one -- without this the wait for
+    // the last requested sample was a wait for everything, the previous block's store included, in every block of the instances that store
+    // at a block's end
+    if constexpr (!kEarlyStore) __builtin_amdgcn_raw_buffer_store_b64(v2f_t{0.f, 0.f}, orsrc, kNoStore, 0, 0);
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     int it = 0;
     float2 none[8];
