@@ -82,7 +82,7 @@ struct BankDecParams {
 // pair; pairs = ceil(n_chunks / 2)), then ceil(n_groups / 4) workgroups of history waves.  (Single-wave workgroups were measured
 // first: the dispatcher put all four of a CU on one SIMD -- 1900 clocks per block instead of 1250; the four waves of one workgroup
 // go to the four SIMDs.)
-template <int NP, int T1, int T2, int T3, int DBG = 0, int MINW = 2, int EARLY = (NP == 4 ? 1 : 0)>
+template <int NP, int T1, int T2, int T3, int DBG = 0, int MINW = 2, int EARLY = (NP == 4 && MINW == 2 ? 1 : 0)>
 static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, const ChanOsc *__restrict__ osc,
                                                                OscDynInline dyn, const float2 *__restrict__ x_hist, float2 *__restrict__ xh_out,
                                                                const float2 *__restrict__ y0_hist, float2 *__restrict__ y0_stage,

@@ -9,10 +9,10 @@ os.environ["PEBBLEGPU_BANK_CLK"] = "0"
 import pebblesdr_amd as P  # noqa: E402
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-fs, C = 2048000, 256
+fs, C = (int(sys.argv[2]) if len(sys.argv) > 2 else 2048000), 256
 rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=k)
 for c in range(C):
-    rx.set_mode(c, P.DM_USB); rx.set_mixer(c, -960e3 + 7.5e3 * c); rx.set_bandpass(c, 300, 3000)
+    rx.set_mode(c, P.DM_USB); rx.set_mixer(c, (-0.45 + 0.9 * c / C) * fs); rx.set_bandpass(c, 300, 3000)
 n = k * rx.superframe
 rng = np.random.default_rng(1)
 x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.05).astype(np.complex64)
