@@ -2011,7 +2011,7 @@ def test_pipelined_calls_run_back_to_back_and_match_joined_calls(gpu_lib, monkey
             bf.free()
 
 
-@pytest.mark.parametrize("fs,C,modes", [(2048000, 64, "usb"), (2048000, 20, "am_usb_fm"), (100000000, 64, "am_usb")])
+@pytest.mark.parametrize("fs,C,modes", [(2048000, 64, "usb"), (2048000, 20, "am_usb_fm"), (100000000, 64, "am_usb"), (2048000, 3, "am_usb_fm"), (10000000, 1, "usb")])
 def test_two_stage_calls_back_to_back_equal_single_stream_calls(gpu_lib, monkeypatch, fs, C, modes):
     """A receiver without a display transform runs every call in two stages on two streams (mixer + decimator | band-pass, AGC,
     demodulators), the second stage beside the NEXT call's decimator, which writes the other of two output buffers; the band-pass's
@@ -2035,13 +2035,14 @@ def test_two_stage_calls_back_to_back_equal_single_stream_calls(gpu_lib, monkeyp
     sf = a.superframe
     lens = [2 * sf, sf, 2 * sf, 2 * sf, sf, 2 * sf, 2 * sf] if fs < 50_000_000 else [sf] * K  # (a super-frame at 100 Msps is 4 M samples)
     x = (tones(fs, sum(lens), [(0.05, fc + 1000.0 + 40.0 * i) for i, fc in enumerate(fcs[:: max(1, C // 8)])]) + lcg_noise(sum(lens), 5, 1e-2)).astype(np.complex64)
+    # (banks of fewer than 16 channels run the general kernels -- first stage, cascade -- on the first stream: the same two-stage calls)
     offs = np.concatenate([[0], np.cumsum(lens)])
     bufs = [P.DeviceBuffer.from_array(P.binding.to_f32_iq(x[offs[k]:offs[k + 1]]), 0) for k in range(K)]
 
     def retune(rx):
-        rx.set_mixer(1, fcs[1] + 700.0)
-        rx.set_mode(2, P.DM_LSB)
-        rx.set_bandpass(2, -3000, -300)
+        rx.set_mixer(min(1, C - 1), fcs[min(1, C - 1)] + 700.0)
+        rx.set_mode(min(2, C - 1), P.DM_LSB)
+        rx.set_bandpass(min(2, C - 1), -3000, -300)
     try:
         want = []
         for k in range(K):
