@@ -195,7 +195,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     const unsigned vmax = (unsigned)(8 * (P.n_in - 1 - (P.max_off - P.min_off)) + 4 * compL);  // the last window that ends inside the call
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(inf), 0, (int)(unsigned)(P.n_in * 8), 0x00020000);
     const int o_safe = (int)(((P.min_off < 0 ? ((long long)(-P.min_off) + S - 1) / S : 0) + 14) / 8);  // S (8 o - 7) + min_off >= 0 from block o_safe on
-    float ld[2 * NP];
+    float ld[2 * NP], ld_alt[2 * NP];  // the fetched samples of the next block (two sets: the main loop alternates them, no copies)
     const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     if (hist_wave) {
@@ -307,7 +307,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     };
     // the raw samples of block `it` of both chunks (block index relative to the chunks' first block); `voff` is that block's
     typedef unsigned v3u_t __attribute__((ext_vector_type(3)));
-    auto fetch_all = [&](int it, auto edgec) {
+    auto fetch_all = [&](int it, auto edgec, float (&ld)[2 * NP]) {
         if constexpr (!decltype(edgec)::value && (DBG & 1) != 0) return;  // (timing experiment: no sample fetches in the plain blocks)
         bool slow = false;
         if constexpr (decltype(edgec)::value) slow = straddles(it);
@@ -366,12 +366,12 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     // prologue: block 0 through the matrix pipe, block 1's samples on their way
     {
         v16f_t acc = zero16;
-        fetch_all(0, std::true_type{});
+        fetch_all(0, std::true_type{}, ld);
 #pragma unroll
         for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]), bco[p], acc, 0, 0, 0);
         D = acc;
         voff += 64u * S;
-        fetch_all(1, std::true_type{});
+        fetch_all(1, std::true_type{}, ld);
         voff += 64u * S;
     }
 
@@ -432,7 +432,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     // samples of block it + 1.  EDGE: the variant for the blocks at the call's start (first-stage outputs in front of the call from the
     // previous call's tail `yq`, requested a block ahead; the slow sample fetches of the straddling blocks); the plain variant is one
     // straight run of code.
-    auto block = [&](int it, auto edgec, float2 (&yq)[8]) {
+    auto block = [&](int it, auto edgec, float2 (&yq)[8], float (&ld_use)[2 * NP], float (&ld_next)[2 * NP]) {
         constexpr bool EDGE = decltype(edgec)::value;
         const int rel = it - WARM;               // block o = o0 + rel = final output o
         const long long o = o0 + rel;
@@ -464,8 +464,8 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         // the A values of block it + 1 at once, then all the requests for block it + 2 (a full block ahead of their use, one wait)
         float av[NP];
 #pragma unroll
-        for (int p = 0; p < NP; p++) av[p] = __builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]);
-        fetch_all(it + 2, edgec);
+        for (int p = 0; p < NP; p++) av[p] = __builtin_fmaf(ca, ld_use[2 * p], cb * ld_use[2 * p + 1]);
+        fetch_all(it + 2, edgec, ld_next);
         voff += 64u * S;
         // The block's store goes out right BEHIND those requests, not at the block's end: loads and stores retire through ONE in-order
         // counter, so the wait for a block's samples is also a wait for every store issued in front of their requests.  At the block's
@@ -612,7 +612,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     int it = 0;
     float2 none[8];
-    if (pair == 0) {  // (uniform)
+    if (pair == 0 && (DBG & 32) == 0) {  // (uniform; DBG 32: timing experiment without the edge blocks)
         // Edge blocks: all blocks up to the last straddling one when the chunks warm up from the first-stage history; with the
         // running sums restored, only the blocks around the restore -- the warm-up blocks in front run plain and what they leave in a
         // chunk that starts at the call's start is overwritten
@@ -622,7 +622,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
             e0 = (L < WARM ? WARM - L : WARM) - 2;  // (L = 16: chunk 1 starts in front of the call as well)
             e0 = e0 < 0 ? 0 : e0;
         }
-        for (; it < e0; it++) block(it, std::false_type{}, none);
+        for (; it < e0; it++) block(it, std::false_type{}, none, ld, ld);
         float2 yq[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) yq[k] = yh[8 * (o0 - WARM + it) - 7 + k];
@@ -638,10 +638,16 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
 #pragma unroll
                 for (int i = 0; i < N3; i++) { const float2 v = st[N1 + N2 + i]; a3[i] = mine ? v : a3[i]; }
             }
-            block(it, std::true_type{}, yq);
+            block(it, std::true_type{}, yq, ld, ld);
         }
     }
-    for (; it < nb; it++) block(it, std::false_type{}, none);
+    // (two blocks per turn with the two sample sets exchanged: from one set the compiler fetched into fixed registers and copied them at
+    // the top of every block)
+    for (; it + 1 < nb; it += 2) {
+        block(it, std::false_type{}, none, ld, ld_alt);
+        block(it + 1, std::false_type{}, none, ld_alt, ld);
+    }
+    if (it < nb) { block(it, std::false_type{}, none, ld, ld); it++; }
     // the running sums where this call ends, for the next call's chunk 0 (L divides n_out: the last chunk is a whole one)
     if (P.state_out != nullptr && 2 * pair + 1 >= P.n_chunks - 1 && chunk_raw == P.n_chunks - 1 && ch_raw < P.n_chan) {
         float2 *st = P.state_out + (long long)c * (N1 + N2 + N3);
