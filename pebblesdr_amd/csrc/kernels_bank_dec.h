@@ -110,6 +110,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     const int pair = hist_wave ? 0 : (wq / gq) * 8 + (blockIdx.x & 7);
     const int grp = hist_wave ? (hq / P.hist_split) * 4 + wv : (wq % gq) * 4 + wv;
     if (pair >= pairs || grp >= P.n_groups) return;  // wave-uniform (no workgroup barrier anywhere below)
+    if constexpr ((DBG & 64) != 0) { if (hist_wave) return; }  // (timing experiment: no history waves)
 
     // ---- D side: this lane's channel and chunk ----
     const int S = P.S, L = P.L;
