@@ -93,6 +93,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY, WARM = G::warm;
     constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
     constexpr bool kEarlyStore = EARLY != 0;  // where a block's store is issued (see the block's code)
+    constexpr int kStoreAux = (DBG & 128) != 0 ? 2 : 0;  // (A/B: nontemporal result stores)
     __shared__ float2 tiles[4][2][16 * 65];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -425,7 +426,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
             row_run += 2;
         }
         // (the scalar offset IS uniform; said so explicitly, or the compiler wraps the store in a loop over the lanes' values)
-        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, __builtin_amdgcn_readfirstlane((int)so_run), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, __builtin_amdgcn_readfirstlane((int)so_run), kStoreAux);
         so_run += so_row2;
     };
 
@@ -675,7 +676,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
                 vo = row_run < ch_lim ? vo : kNoStore;
                 row_run += 2;
             }
-            __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, (int)so_run, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v2f_t{sv.x, sv.y}, orsrc, vo, (int)so_run, kStoreAux);
             so_run += so_row2;
         }
     }
