@@ -369,7 +369,7 @@ static const std::vector<BankVariant> &bank_variants()
 {
     static const std::vector<BankVariant> v = {
         bank_variant_of<4, 15, 19, 31, 2>(),  bank_variant_of<4, 15, 23, 43, 2>(),  bank_variant_of<4, 15, 23, 47, 2>(),  bank_variant_of<4, 15, 19, 35, 2>(),
-        bank_variant_of<4, 15, 27, 59, 1>(),  bank_variant_of<4, 19, 27, 59, 1>(),
+        bank_variant_of<4, 15, 27, 59, 2>(),  bank_variant_of<4, 19, 27, 59, 2>(),  // (227 / 231 registers since the main loop stopped copying its fetched samples: half a SIMD's file)
         bank_variant_of<12, 15, 23, 47, 1>(), bank_variant_of<12, 15, 19, 35, 1>(), bank_variant_of<12, 15, 27, 59, 1>(),
     };
     return v;
