@@ -500,6 +500,9 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
             kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 2> : dbg == 3 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 3>
                  : dbg == 4 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 4> : dbg == 8 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 16>
                  : dbg == 128 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 128> : dbg == 32 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 32> : dbg == 64 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 64> : dbg == 96 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 96> : dbg == 31 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 31> : dbg == 100 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 0, 1> : kern;
+        if (dbg && bv->t1 == 19 && bv->t2 == 27 && bv->t3 == 59)
+            kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 2> : dbg == 4 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 4>
+                 : dbg == 8 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 16> : dbg == 31 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 31> : kern;
         if (int rc = launch_bank<4>(kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp)) return rc;
     } else {
         // CIC3 at stride S0 in the reference's merged form (decimator.cpp:719-737: output k = .125 (od_k + ev_{k-1} + 3 (od_{k-1} + ev_k)) of the
