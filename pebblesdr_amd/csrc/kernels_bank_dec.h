@@ -193,9 +193,10 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     // arithmetic in the loop.  The offset is clamped into the buffer: windows that reach in front of the call or past its end belong
     // to outputs nobody uses (chunk 0's warm-up blocks take the previous call's first-stage history; the output one past the call's
     // end) -- except the first o_safe blocks of the call proper, whose windows straddle the call's first sample: those go through
-    // the slow path that picks the previous call's raw tail (`straddles`).
+    // the edge variant of the fetch, which requests every value from the call and from the previous call's raw tail and selects.
     const unsigned vmax = (unsigned)(8 * (P.n_in - 1 - (P.max_off - P.min_off)) + 4 * compL);  // the last window that ends inside the call
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(inf), 0, (int)(unsigned)(P.n_in * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_xh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xhf), 0, (int)(unsigned)(P.xh * 8), 0x00020000);
     const int o_safe = (int)(((P.min_off < 0 ? ((long long)(-P.min_off) + S - 1) / S : 0) + 14) / 8);  // S (8 o - 7) + min_off >= 0 from block o_safe on
     float ld[2 * NP], ld_alt[2 * NP];  // the fetched samples of the next block (two sets: the main loop alternates them, no copies)
     const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -302,18 +303,49 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     const long long oA_start = (long long)chunkA * L - WARM;
     // (modulo 2^32: exact wherever it is used unclamped -- the host sends calls of 4 GiB or more down the other routes)
     unsigned voff = (unsigned)(4 * (2LL * S * (8 * oA_start - 7 + kA) + compL + 2LL * P.min_off));
-    // (uniform) block `it` holds outputs whose windows straddle the call's first sample: chunk 0 at o = 0 .. o_safe - 1, and chunk 1
-    // when it is shorter than the warm-up (L = 16)
-    auto straddles = [&](int it) {
-        return pair == 0 && ((it >= WARM && it < WARM + o_safe) || (it >= WARM - L && it < WARM - L + o_safe));
-    };
     // the raw samples of block `it` of both chunks (block index relative to the chunks' first block); `voff` is that block's
     typedef unsigned v3u_t __attribute__((ext_vector_type(3)));
     auto fetch_all = [&](int it, auto edgec, float (&ld)[2 * NP]) {
         if constexpr (!decltype(edgec)::value && (DBG & 1) != 0) return;  // (timing experiment: no sample fetches in the plain blocks)
-        bool slow = false;
-        if constexpr (decltype(edgec)::value) slow = straddles(it);
-        if (!slow) {
+        if constexpr (decltype(edgec)::value && NP == 4) {
+            // The blocks at the call's start (chunk pair 0 only): every value on its own -- from the call (index clamped into it) AND
+            // from the previous call's raw tail (clamped into that), selected by the sign of its index.  No branch: with a branch
+            // around a slower path the compiler knew no count of the requests in flight and every one of these blocks drained them all,
+            // the ones it had just issued included.
+            const int sj = S * (8 * (int)(oA_start + it) - 7 + kA);
+            const int n_in_i = (int)P.n_in;  // (the host keeps calls under 4 GiB)
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int i = sj + (q == 0 ? P.oa[p] : P.ob[p]);
+                    int ia = i < 0 ? 0 : i;
+                    ia = ia < n_in_i ? ia : n_in_i - 1;
+                    int ib = P.xh + i;
+                    ib = ib < 0 ? 0 : ib;
+                    ib = ib < P.xh ? ib : P.xh - 1;
+                    const float va = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, 8u * (unsigned)ia + 4u * (unsigned)compL, 0, 0));
+                    const float vb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_xh, 8u * (unsigned)ib + 4u * (unsigned)compL, 0, 0));
+                    ld[2 * p + q] = i < 0 ? vb : va;
+                }
+            }
+        } else if (decltype(edgec)::value && pair == 0 &&
+                   ((it >= WARM && it < WARM + o_safe) || (it >= WARM - L && it < WARM - L + o_safe))) {
+            // (the CIC front keeps the branch: twenty-four values a block, each with two requests, cost its edge blocks more than the
+            // drain does -- configs[3] on one stream 0.117 -> 0.134 ms with the branch-free form)
+            const long long sj = (long long)S * (8 * (oA_start + it) - 7 + kA);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    long long i = sj + (q == 0 ? P.oa[p] : P.ob[p]);
+                    i = i < P.n_in ? i : P.n_in - 1;
+                    long long ih = (long long)P.xh + i;  // in front of the call: the previous call's tail (never used when older than that)
+                    ih = ih > 0 ? ih : 0;
+                    ld[2 * p + q] = i >= 0 ? inf[2 * i + compL] : xhf[2 * ih + compL];
+                }
+            }
+        } else {
             const unsigned vc = voff < vmax ? voff : vmax;
             if constexpr (NP == 12) {
                 // A merged CIC3 in front: its window is twelve sample pairs x[S0 t], x[S0 t + 1] (t = 0 .. 11 from the window's first sample),
@@ -339,19 +371,6 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
                     ld[2 * p + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vc, 8 * (P.ob[p] - P.min_off), 0));
                 }
             }
-        } else {
-            const long long sj = (long long)S * (8 * (oA_start + it) - 7 + kA);
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    long long i = sj + (q == 0 ? P.oa[p] : P.ob[p]);
-                    i = i < P.n_in ? i : P.n_in - 1;
-                    long long ih = (long long)P.xh + i;  // in front of the call: the previous call's tail (never used when older than that)
-                    ih = ih > 0 ? ih : 0;
-                    ld[2 * p + q] = i >= 0 ? inf[2 * i + compL] : xhf[2 * ih + compL];
-                }
-            }
         }
     };
     v16f_t D;
@@ -368,12 +387,14 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     // prologue: block 0 through the matrix pipe, block 1's samples on their way
     {
         v16f_t acc = zero16;
-        fetch_all(0, std::true_type{}, ld);
+        if (pair == 0) fetch_all(0, std::true_type{}, ld);
+        else fetch_all(0, std::false_type{}, ld);
 #pragma unroll
         for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_fmaf(ca, ld[2 * p], cb * ld[2 * p + 1]), bco[p], acc, 0, 0, 0);
         D = acc;
         voff += 64u * S;
-        fetch_all(1, std::true_type{}, ld);
+        if (pair == 0) fetch_all(1, std::true_type{}, ld);
+        else fetch_all(1, std::false_type{}, ld);
         voff += 64u * S;
     }
 
@@ -618,7 +639,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
         // Edge blocks: all blocks up to the last straddling one when the chunks warm up from the first-stage history; with the
         // running sums restored, only the blocks around the restore -- the warm-up blocks in front run plain and what they leave in a
         // chunk that starts at the call's start is overwritten
-        int e0 = 0, e_lo = WARM + 1 + o_safe;
+        int e0 = 0, e_lo = WARM + 1;  // (the last block that needs the edge variant is o = 0: the straddling windows of blocks o = 0 .. o_safe - 1 are requested two blocks earlier)
         if (e_lo > nb) e_lo = nb;
         if (P.state_in != nullptr) {
             e0 = (L < WARM ? WARM - L : WARM) - 2;  // (L = 16: chunk 1 starts in front of the call as well)
