@@ -2287,3 +2287,41 @@ def test_pinned_ingest_slots_on_a_bank(gpu_lib):
         finally:
             buf.free()
     assert np.abs(gb).max() > 1e-3 and np.array_equal(ga, gb)
+
+
+def test_two_stage_calls_interleaved_with_single_stream_calls(gpu_lib, monkeypatch):
+    """A receiver that alternates between its two call shapes on a running stream: two-stage calls (stage 2 on the other stream,
+    alternating output buffers, no tail launch between two bank kernels) and single-stream calls (per-kernel profiling on: every kernel
+    on one stream) -- the histories each shape leaves are the ones the other picks up (first-stage staging buffers, the band-pass's
+    look-back in the other output buffer, the oscillators advanced by the bank kernel or by the tail launch).  Eight calls queued
+    without synchronisation against a receiver that only ever makes single-stream calls: bit for bit."""
+    import pebblesdr_amd as P
+    fs, C = 2048000, 48
+    monkeypatch.setenv("PEBBLEGPU_BANK_PIPELINE", "0")
+    b = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    monkeypatch.delenv("PEBBLEGPU_BANK_PIPELINE")
+    a = P.ReceiverBank(fs, C, True, False, 0, max_superframes=2)
+    fcs = [(-0.4 + 0.8 * (c + 0.5) / C) * fs for c in range(C)]
+    for rx in (a, b):
+        for c in range(C):
+            m = P.DM_AM if c % 3 == 0 else P.DM_USB
+            rx.set_mode(c, m); rx.set_mixer(c, fcs[c])
+            rx.set_bandpass(c, 300, 3000) if m == P.DM_USB else rx.set_bandpass(c, -4000, 4000)
+    sf = a.superframe
+    K = 8
+    x = (tones(fs, K * sf, [(0.05, fc + 1200.0) for fc in fcs[::6]]) + lcg_noise(K * sf, 12, 1e-2)).astype(np.complex64)
+    bufs = [P.DeviceBuffer.from_array(P.binding.to_f32_iq(x[k * sf:(k + 1) * sf]), 0) for k in range(K)]
+    try:
+        for k in range(K):
+            b.process_device(bufs[k].ptr, sf)
+        want = b.audio()
+        prof = [False, False, True, False, False, True, True, False]
+        for k in range(K):
+            a.set_profiling(prof[k])
+            a.process_device(bufs[k].ptr, sf)
+        got = a.audio()
+        assert np.abs(want).max() > 1e-3 and np.array_equal(got, want)
+        assert a.kernel_name(2) == "k_mix_dec_mfma"
+    finally:
+        for bf in bufs:
+            bf.free()
