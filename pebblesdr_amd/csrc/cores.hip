@@ -422,7 +422,9 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
     // One wave per SIMD pays the fewest warm-up blocks; two overlap what a lone wave leaves idle (measured on hb11 x 4, 15/19/31: 1200
     // clocks per block alone, 2075 for each of two) -- worth it once a chunk is long against its warm-up: from 128 outputs per chunk on
     int waves = bank_waves;
-    if (waves == 0) waves = cdiv(len_out, 2 * std::max(1LL, 1024LL / g32)) >= 128 ? 2 : 1;
+    // (a receiver that runs two-stage calls keeps one wave per SIMD at every batch size: the previous call's band-pass needs the other
+    // half of the register file beside it -- 0.2385 ms per configs[2] call of 32 super-frames against 0.2546, 0.875 against 0.905 at 128)
+    if (waves == 0) waves = (!fin2.base && cdiv(len_out, 2 * std::max(1LL, 1024LL / g32)) >= 128) ? 2 : 1;
     if (waves > bv->minw) waves = bv->minw;  // (the instances with the longest halfbands need more than half a SIMD's registers)
     long long pairs_target = 1024LL * waves / g32;
     if (cic) pairs_target /= 2;  // (twelve pairs of lines per output instead of one window: the blocks are bound by what they fetch, and every chunk

@@ -12,6 +12,7 @@ import pebblesdr_amd as P  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "2"
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 fs, C, modes, k = (2048000, 256, [P.DM_USB], 8) if which == "2" else (100000000, 512, [P.DM_AM, P.DM_USB], 1)
+k = int(sys.argv[3]) if len(sys.argv) > 3 else k  # super-frames per call
 rx = P.ReceiverBank(fs, C, True, False, 0, max_superframes=k)
 for c in range(C):
     rx.set_mode(c, modes[c % len(modes)])
@@ -33,4 +34,4 @@ for rep in range(3):
     rx.synchronize()
     best = min(best, (time.perf_counter() - t0) / calls * 1e3)
     host = min(host, (t1 - t0) / calls * 1e3)
-print("configs[%s] PEBBLEGPU_BANK_PIPELINE=%s: %.4f ms per call, the host queues one in %.4f ms (%s)" % (which, os.environ.get("PEBBLEGPU_BANK_PIPELINE", "unset"), best, host, rx.kernel_name(2)))
+print("configs[%s] k=%d PEBBLEGPU_BANK_PIPELINE=%s: %.4f ms per call, the host queues one in %.4f ms (%s)" % (which, k, os.environ.get("PEBBLEGPU_BANK_PIPELINE", "unset"), best, host, rx.kernel_name(2)))
