@@ -501,7 +501,7 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
         if (dbg && bv->t1 == 15 && bv->t2 == 19 && bv->t3 == 31)
             kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 2> : dbg == 3 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 3>
                  : dbg == 4 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 4> : dbg == 8 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 16>
-                 : dbg == 128 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 128> : dbg == 32 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 32> : dbg == 64 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 64> : dbg == 96 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 96> : dbg == 31 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 31> : dbg == 100 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 0, 1> : kern;
+                 : dbg == 128 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 128> : dbg == 256 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 256> : dbg == 512 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 512> : dbg == 32 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 32> : dbg == 64 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 64> : dbg == 96 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 96> : dbg == 31 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 31> : dbg == 100 ? (void *)k_mix_dec_mfma<4, 15, 19, 31, 0, 1> : kern;
         if (dbg && bv->t1 == 19 && bv->t2 == 27 && bv->t3 == 59)
             kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 2> : dbg == 4 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 4>
                  : dbg == 8 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 16> : dbg == 31 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 31> : kern;

@@ -93,7 +93,7 @@ static __global__ __launch_bounds__(256, MINW) void k_mix_dec_mfma(const float2 
     constexpr int N1 = G::N1, N2 = G::N2, N3 = G::N3, HY = G::HY, WARM = G::warm;
     constexpr int PC1 = (T1 - 1) / 2, PC2 = (T2 - 1) / 2, PC3 = (T3 - 1) / 2;
     constexpr bool kEarlyStore = EARLY != 0;  // where a block's store is issued (see the block's code)
-    constexpr int kStoreAux = (DBG & 128) != 0 ? 2 : 0;  // (A/B: nontemporal result stores)
+    constexpr int kStoreAux = (DBG & 128) != 0 ? 2 : (DBG & 256) != 0 ? 1 : (DBG & 512) != 0 ? 17 : 0;  // (A/B: nontemporal / sc0 / sc0 sc1 result stores)
     __shared__ float2 tiles[4][2][16 * 65];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
