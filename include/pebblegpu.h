@@ -151,8 +151,22 @@ int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_h
  * within the first blocks on every input it has been tried on (pinned on the oracle's line-by-line restatement with clean, noisy,
  * weak and absent pilots at the demodulator rates the receiver runs, tests/test_oracle_pins.py -- other inputs: parity unpinned);
  * the library runs the loop, serially per channel, until the first block that ends without lock and treats the stream as mono from
- * there (the lock average would need seconds of a quiet detector to come back).  Not reproduced: the RDS bit decoder (GUI text). */
+ * there (the lock average would need seconds of a quiet detector to come back).  The RDS branch of the same function (:296-357:
+ * m_RdsDownConvert, the 2400 Hz low-pass, processRdsPll, the biphase matched filter, the bit-rate resonator and slicer,
+ * processNewRdsBit's block synchroniser with its burst corrector) runs for every dmFMS channel, in double on the device; its groups are
+ * read through pebblegpu_receiver_rds_groups.  Calls and frames of a dmFMS bank must be multiples of the RDS down-converter's
+ * decimation (16 or 32) and at least as long as its widest stage.  Not reproduced: what the GUI makes of a group (rdsdecode.cpp). */
 int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
+/* tRDS_GROUPS (application/demod/rbdsconstants.h) */
+typedef struct pebblegpu_rds_group { uint16_t block_a, block_b, block_c, block_d; } pebblegpu_rds_group;
+/* int Demod_WFM::getNextRdsGroupData(tRDS_GROUPS *), demod_wfm.h:39, as its one caller uses it (Demod::fmStereo, demod.cpp:196-226:
+ * ONE call behind every processDataStereo, i.e. per frame of frames_per_buffer demodulator samples): the groups that caller would
+ * have taken from m_RdsGroupQueue (RDS_Q_SIZE 100, cleared and stuffed with a zero group after BLOCK_ERROR_LIMIT bad blocks) over the
+ * frames processed since the last call of this function, oldest first, and for each the function's return value -- changed[i] != 0:
+ * the group differs from the one delivered before it (only those reach the reference's text decoder, and only when block_a != 0).
+ * Waits for the receiver's queued work.  *n: entries written (<= cap; the rest stays for the next call). */
+int pebblegpu_receiver_rds_groups(pebblegpu_receiver *rx, uint32_t channel, pebblegpu_rds_group *groups, uint8_t *changed, uint32_t cap,
+                                  uint32_t *n);
 /* AGC::setAgcMode(mode, threshold) (application/agc.cpp:53-82; Receiver::agcModeChanged/agcThresholdChanged).
  * agc_mode: the reference's AgcMode values.  With PEBBLEGPU_AGC_OFF the threshold is a manual gain slider in dB
  * (amplitude 10^((threshold/5)/20), integer division as written, agc.cpp:239-246; the constructor's OFF/1 is unit
@@ -372,6 +386,10 @@ int pebblegpu_demod_set_bandwidth(pebblegpu_demod *d, double bw);    /* demod.cp
 /* CPX *Demod::processBlock(CPX *in, int n), application/demod.h:33: *out = library buffer, or = in for the
  * pass-through modes (demod.cpp:127-138) */
 int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const double **out);
+/* dmFMS: getNextRdsGroupData as above, a processBlock call being one frame; and m_RdsData (the matched filter's output the bit
+ * slicer reads, demod_wfm.cpp:309) of the last processBlock call: *n its length, at most cap values copied */
+int pebblegpu_demod_rds_groups(pebblegpu_demod *d, pebblegpu_rds_group *groups, uint8_t *changed, uint32_t cap, uint32_t *n);
+int pebblegpu_demod_rds_signal(pebblegpu_demod *d, double *data, uint32_t cap, uint32_t *n);
 
 typedef struct pebblegpu_spectrum pebblegpu_spectrum;
 /* FFT::factory + fftParams(fftSize, 0, sampleRate, samplesPerBuffer, BLACKMANHARRIS), fft.cpp:45-118 */

@@ -93,6 +93,14 @@ def lib():
         L.po_nb1_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.po_nb2_process.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.po_receiver_set_audio_rate.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_demod_wfm_rds_rate.restype = C.c_double
+        L.po_demod_wfm_rds_rate.argtypes = [C.c_void_p]
+        L.po_demod_wfm_rds_last.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.po_demod_wfm_rds_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.po_demod_wfm_rds_pushed.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.po_demod_wfm_next_rds_group.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_demod_wfm_free.argtypes = [C.c_void_p]
+        L.po_receiver_rds_polled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.po_fd_estimate.restype = C.c_double
         L.po_fd_estimate.argtypes = [_dp, C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_double, _dp]
         L.po_agc_new.restype = C.c_void_p
@@ -422,7 +430,11 @@ class _WfmS(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fs", "d1_re", "d1_im", "deemph_alpha", "deemph_re", "deemph_im")] + \
                [("mono_lp", _IirS), ("notch", _IirS), ("lp", _FirS), ("hilbert", _FirS), ("pilot_bp", _IirS)] + \
                [(n, C.c_double) for n in ("nco_phase", "nco_freq", "nco_lo", "nco_hi", "pll_alpha", "pll_beta", "err_ave", "err_alpha",
-                                          "phase_adjust")] + [("pilot_locked", C.c_int)]
+                                          "phase_adjust")] + [("pilot_locked", C.c_int), ("rds", C.c_void_p)]
+
+
+class _RdsGroup(C.Structure):
+    _fields_ = [(n, C.c_uint16) for n in ("a", "b", "c", "d")]
 
 
 class DemodWFM:
@@ -448,6 +460,45 @@ class DemodWFM:
         out = np.empty_like(x)
         locked = lib().po_demod_wfm_process_stereo(C.byref(self.s), _ptr(x), _ptr(out), C.c_int(len(x)))
         return out, bool(locked)
+
+    def __del__(self):
+        try:
+            lib().po_demod_wfm_free(C.byref(self.s))
+        except Exception:
+            pass
+
+    # the RDS branch of processDataStereo (demod_wfm.cpp:296-357, 488-786)
+    @property
+    def rds_rate(self):
+        return lib().po_demod_wfm_rds_rate(C.byref(self.s))
+
+    def rds_last(self):
+        """(m_RdsData, bit-sync resonator output) of the last process_stereo call"""
+        n = lib().po_demod_wfm_rds_last(C.byref(self.s), None, None, 0)
+        data = np.empty(n, dtype=np.float64)
+        sync = np.empty(n, dtype=np.float64)
+        lib().po_demod_wfm_rds_last(C.byref(self.s), _ptr(data), _ptr(sync), n)
+        return data, sync
+
+    def rds_bits(self):
+        """the bits handed to processNewRdsBit since the last call of this method"""
+        buf = np.empty(1 << 20, dtype=np.uint8)
+        n = lib().po_demod_wfm_rds_bits(C.byref(self.s), buf.ctypes.data_as(C.c_void_p), len(buf))
+        return buf[:n].copy()
+
+    def rds_pushed(self):
+        """the groups put into m_RdsGroupQueue since the last call of this method, (n, 4) uint16; a cleared queue shows as a zero group"""
+        arr = (_RdsGroup * 4096)()
+        n = lib().po_demod_wfm_rds_pushed(C.byref(self.s), arr, 4096)
+        return np.array([[g.a, g.b, g.c, g.d] for g in arr[:n]], dtype=np.uint16).reshape(-1, 4)
+
+    def next_rds_group(self):
+        """getNextRdsGroupData: None when the queue is empty, else ((a, b, c, d), changed)"""
+        g = _RdsGroup()
+        ch = C.c_int(0)
+        if not lib().po_demod_wfm_next_rds_group(C.byref(self.s), C.byref(g), C.byref(ch)):
+            return None
+        return (g.a, g.b, g.c, g.d), bool(ch.value)
 
 
 def fd_estimate(spectrum_db, spectrum_rate, bp_lo, bp_hi, mixer_freq):
@@ -578,6 +629,13 @@ class Receiver:
 
     def dec_stages(self, wfm=False):
         return lib().po_receiver_dec_stages(self.h, 1 if wfm else 0)
+
+    def rds_polled(self):
+        """dmFMS: the groups Demod::fmStereo popped since the last call of this method -> ((n, 4) uint16, (n,) bool changed)"""
+        arr = (_RdsGroup * 4096)()
+        ch = np.zeros(4096, dtype=np.uint8)
+        n = lib().po_receiver_rds_polled(self.h, arr, ch.ctypes.data_as(C.c_void_p), 4096)
+        return np.array([[g.a, g.b, g.c, g.d] for g in arr[:n]], dtype=np.uint16).reshape(-1, 4), ch[:n].astype(bool)
 
     def set_agc(self, mode, threshold):
         lib().po_receiver_set_agc(self.h, int(mode), int(threshold))

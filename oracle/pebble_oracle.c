@@ -860,6 +860,245 @@ int po_downconvert_process(po_downconvert *d, int n, const double *in, double *o
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * RDS branch of Demod_WFM -- application/demod/demod_wfm.cpp:296-357 (in processDataStereo), 488-761; constants of
+ * application/demod/rbdsconstants.h.  Up to the group queue; what the GUI makes of a group (rdsdecode.cpp) is not restated
+ * ---------------------------------------------------------------------------------------------- */
+static double po_wfm_arctan2(double y, double x);
+#define PO_RDS_Q_SIZE 100                       /* RDS_Q_SIZE, demod_wfm.h:21 */
+#define PO_RDS_BITRATE (57000.0 / 48.0)         /* RDS_BITRATE */
+static const uint32_t po_rds_parckh[16] = {     /* PARCKH, rbdsconstants.h: the last 16 rows of the parity-check matrix */
+    0x2DC, 0x16E, 0x0B7, 0x287, 0x39F, 0x313, 0x355, 0x376, 0x1BB, 0x201, 0x3DC, 0x1EE, 0x0F7, 0x2A7, 0x38F, 0x31B
+};
+static const uint32_t po_rds_blk_offset[8] = {  /* BLK_OFFSET_TBL: syndromes of offset words A B C D, A B C' D */
+    0x3D8, 0x3D4, 0x25C, 0x258, 0x3D8, 0x3D4, 0x3CC, 0x258
+};
+struct po_rds {
+    double rate;
+    po_downconvert dc;                          /* m_RdsDownConvert: SetDataRate(fs, 8000), SetFrequency(-57000), :187-188 */
+    po_fir lp;                                  /* m_RdsBPFilter, :496 */
+    double mcoef[2 * 75], mz[75];               /* m_RdsMatchedFilter: InitConstFir keeps m_Coef only, the real ProcessFilter uses it */
+    int mtaps, mstate;
+    po_iir bitsync;                             /* m_RdsBitSyncFilter, :522 */
+    double nco_phase, nco_freq, nco_lo, nco_hi, pll_alpha, pll_beta; /* :492-503 */
+    double last_sync, last_sync_slope, last_data;
+    int last_bit;
+    uint32_t in_bits;                           /* m_InBitStream */
+    int bit_pos, cur_block, state, bgroup, block_errors;
+    uint16_t block[4];
+    po_rds_group q[PO_RDS_Q_SIZE], last_group;
+    int qhead, qtail;
+    /* for the tests: the last call's signals and what happened since the last drain */
+    double *data, *sync; int n_last, cap_last;
+    uint8_t *bits; int n_bits, cap_bits;
+    po_rds_group *pushed; int n_pushed, cap_pushed;
+};
+static void po_rds_init(struct po_rds *r, double fs) /* setSampleRate :187-191 and initRds :490-537 */
+{
+    memset(r, 0, sizeof(*r));
+    r->dc.in_rate = 100000.0; r->dc.max_bw = 10000.0; r->dc.osc1_re = 1.0;  /* CDownConvert's constructor, downconvert.cpp:63-77 */
+    r->rate = po_downconvert_set_data_rate(&r->dc, fs, 8000.0, 0);
+    po_downconvert_set_frequency(&r->dc, -57000.0);
+    po_fir_init_lp(&r->lp, 0, 1.0, 40.0, 2400.0, 1.3 * 2400.0, r->rate);
+    const double norm = PO_TWOPI / r->rate;
+    r->nco_lo = (0.0 - 12.0) * norm;                        /* RDSPLL_RANGE 12 */
+    r->nco_hi = (0.0 + 12.0) * norm;
+    r->pll_alpha = 2.0 * .707 * 1.0 * norm;                 /* RDSPLL_ZETA .707, RDSPLL_BW 1 */
+    r->pll_beta = (r->pll_alpha * r->pll_alpha) / (4.0 * .707 * .707);
+    int len = (int)(r->rate / PO_RDS_BITRATE);              /* m_MatchCoefLength = SampleRate / RDS_BITRATE, an int */
+    double coef[2 * 75 + 2];
+    memset(coef, 0, sizeof(coef));
+    for (int i = 0; i <= len; i++) {                        /* :508-517, as written (i = 0 divides by zero: 1/inf = 0, and -0 is stored last) */
+        const double t = (double)i / r->rate, x = t * PO_RDS_BITRATE, x64 = 64.0 * x;
+        coef[i + len] = .75 * cos(2.0 * PO_TWOPI * x) * ((1.0 / (1.0 / x - x64)) - (1.0 / (9.0 / x - x64)));
+        coef[len - i] = -.75 * cos(2.0 * PO_TWOPI * x) * ((1.0 / (1.0 / x - x64)) - (1.0 / (9.0 / x - x64)));
+    }
+    len *= 2;                                               /* :518: the filter takes 2 len of the 2 len + 1 values */
+    r->mtaps = len > 75 ? 75 : len;                         /* InitConstFir, fir.cpp:176-197 (MAX_NUMCOEF) */
+    for (int i = 0; i < r->mtaps; i++) { r->mcoef[i] = coef[i]; r->mcoef[r->mtaps + i] = coef[i]; }
+    po_iir_init_bp(&r->bitsync, PO_RDS_BITRATE, 500, r->rate);
+    r->last_data = 0.0;                                     /* m_RdsLastData is never initialised in the reference; it decides one bit at most */
+}
+static void po_rds_log_push(struct po_rds *r, po_rds_group g)
+{
+    if (r->n_pushed == r->cap_pushed) {
+        r->cap_pushed = r->cap_pushed ? 2 * r->cap_pushed : 64;
+        r->pushed = (po_rds_group *)realloc(r->pushed, (size_t)r->cap_pushed * sizeof(po_rds_group));
+    }
+    r->pushed[r->n_pushed++] = g;
+}
+/* Demod_WFM::checkBlock, :708-757 */
+static uint32_t po_rds_check_block(struct po_rds *r, uint32_t syndrome_offset, int use_fec)
+{
+    uint32_t testblock = (0x3FFFFFF & r->in_bits);
+    uint32_t syndrome = testblock >> 16;
+    for (int i = 0; i < 16; i++) {
+        if (testblock & 0x8000) syndrome ^= po_rds_parckh[i];
+        testblock <<= 1;
+    }
+    syndrome ^= syndrome_offset;
+    if (syndrome && use_fec) {
+        uint32_t correctmask = (1u << (26 - 1));
+        for (int i = 0; i < 16; i++) { /* Meggitt decoder: bursts of up to five bits */
+            if (syndrome & 0x200) {
+                if (0 == (syndrome & 0x1F)) {
+                    r->in_bits ^= correctmask;
+                    syndrome <<= 1;
+                } else {
+                    syndrome <<= 1;
+                    syndrome ^= 0x5B9; /* CRC_POLY */
+                }
+            } else {
+                syndrome <<= 1;
+            }
+            correctmask >>= 1;
+        }
+        syndrome &= 0x3FF;
+    }
+    return syndrome;
+}
+static void po_rds_queue_group(struct po_rds *r)
+{
+    po_rds_group g = {r->block[0], r->block[1], r->block[2], r->block[3]};
+    r->q[r->qhead++] = g;
+    if (r->qhead >= PO_RDS_Q_SIZE) r->qhead = 0;
+    po_rds_log_push(r, g);
+}
+/* Demod_WFM::processNewRdsBit, :576-700 (states STATE_BITSYNC 0, BLOCKSYNC 1, GROUPDECODE 2, GROUPRESYNC 3) */
+static void po_rds_new_bit(struct po_rds *r, int bit)
+{
+    if (r->n_bits == r->cap_bits) {
+        r->cap_bits = r->cap_bits ? 2 * r->cap_bits : 1024;
+        r->bits = (uint8_t *)realloc(r->bits, (size_t)r->cap_bits);
+    }
+    r->bits[r->n_bits++] = (uint8_t)bit;
+    r->in_bits = (r->in_bits << 1) | (uint32_t)bit;
+    switch (r->state) {
+    case 0:
+        if (0 == po_rds_check_block(r, 0x3D8, 0)) {
+            r->bit_pos = 0;
+            r->bgroup = 0;
+            r->block[0] = (uint16_t)(r->in_bits >> 10);
+            r->cur_block = 1;
+            r->state = 1;
+        }
+        break;
+    case 1:
+        r->bit_pos++;
+        if (r->bit_pos >= 26) {
+            r->bit_pos = 0;
+            if (po_rds_check_block(r, po_rds_blk_offset[r->cur_block + r->bgroup], 0)) {
+                r->state = 0;
+            } else {
+                r->block[r->cur_block] = (uint16_t)(r->in_bits >> 10);
+                if ((1 == r->cur_block) && (r->block[r->cur_block] & 0x0800)) r->bgroup = 4; /* GROUPB_BIT */
+                else r->bgroup = 0;
+                if (r->cur_block >= 3) {
+                    po_rds_queue_group(r);
+                    r->cur_block = 0;
+                    r->block_errors = 0;
+                    r->state = 2;
+                } else {
+                    r->cur_block++;
+                }
+            }
+        }
+        break;
+    case 2:
+        r->bit_pos++;
+        if (r->bit_pos >= 26) {
+            r->bit_pos = 0;
+            if (po_rds_check_block(r, po_rds_blk_offset[r->cur_block + r->bgroup], 1)) { /* USE_FEC 1 */
+                r->block_errors++;
+                if (r->block_errors > 5) { /* BLOCK_ERROR_LIMIT */
+                    const po_rds_group zero = {0, 0, 0, 0};
+                    r->qhead = r->qtail = 0;
+                    r->q[r->qhead++] = zero;
+                    po_rds_log_push(r, zero);
+                    r->state = 0;
+                } else {
+                    r->cur_block++;
+                    if (r->cur_block > 3) r->cur_block = 0;
+                    if (0 != r->cur_block) r->state = 3;
+                }
+            } else {
+                r->block[r->cur_block] = (uint16_t)(r->in_bits >> 10);
+                if ((1 == r->cur_block) && (r->block[r->cur_block] & 0x0800)) r->bgroup = 4;
+                else r->bgroup = 0;
+                r->cur_block++;
+                if (r->cur_block > 3) {
+                    po_rds_queue_group(r);
+                    r->cur_block = 0;
+                    r->block_errors = 0;
+                }
+            }
+        }
+        break;
+    case 3:
+        r->bit_pos++;
+        if (r->bit_pos >= 26) {
+            r->bit_pos = 0;
+            r->cur_block++;
+            if (r->cur_block > 3) {
+                r->cur_block = 0;
+                r->state = 2;
+            }
+        }
+        break;
+    }
+}
+/* the RDS lines of processDataStereo, :296-357, on m_CpxRawFm (n complex values; the down-converter mixes them in place) */
+static void po_rds_process(struct po_rds *r, int n, const double *cpx)
+{
+    double *raw = (double *)malloc((size_t)n * 2 * sizeof(double));
+    const int len = po_downconvert_process(&r->dc, n, cpx, raw);      /* :297 */
+    po_fir_process_cpx(&r->lp, len, raw, raw);                        /* :301 */
+    if (r->cap_last < len) {
+        r->cap_last = len;
+        r->data = (double *)realloc(r->data, (size_t)len * sizeof(double));
+        r->sync = (double *)realloc(r->sync, (size_t)len * sizeof(double));
+    }
+    double *mag = r->sync, *data = r->data;
+    for (int i = 0; i < len; i++) { /* processRdsPll, :542-569 (fsincos there; sin and cos here) */
+        const double sn = sin(r->nco_phase), cs = cos(r->nco_phase);
+        const double tr = cs * raw[2 * i] - sn * raw[2 * i + 1];
+        const double ti = cs * raw[2 * i + 1] + sn * raw[2 * i];
+        const double err = -po_wfm_arctan2(ti, tr);
+        r->nco_freq += (r->pll_beta * err);
+        if (r->nco_freq > r->nco_hi) r->nco_freq = r->nco_hi;
+        else if (r->nco_freq < r->nco_lo) r->nco_freq = r->nco_lo;
+        r->nco_phase += (r->nco_freq + r->pll_alpha * err);
+        mag[i] = ti;
+    }
+    r->nco_phase = fmod(r->nco_phase, PO_TWOPI);
+    for (int i = 0; i < len; i++) { /* m_RdsMatchedFilter.ProcessFilter (real), fir.cpp:77-95 */
+        r->mz[r->mstate] = mag[i];
+        const double *h = &r->mcoef[r->mtaps - r->mstate];
+        double acc = h[0] * r->mz[0];
+        for (int j = 1; j < r->mtaps; j++) acc += h[j] * r->mz[j];
+        if (--r->mstate < 0) r->mstate += r->mtaps;
+        data[i] = acc;
+    }
+    for (int i = 0; i < len; i++) { /* :312-317: square, then the resonator (real CIir::ProcessFilter, iir.cpp:173-182) */
+        const double w0 = data[i] * data[i] - r->bitsync.a1 * r->bitsync.w1a - r->bitsync.a2 * r->bitsync.w2a;
+        mag[i] = r->bitsync.b0 * w0 + r->bitsync.b1 * r->bitsync.w1a + r->bitsync.b2 * r->bitsync.w2a;
+        r->bitsync.w2a = r->bitsync.w1a; r->bitsync.w1a = w0;
+    }
+    for (int i = 0; i < len; i++) { /* :320-353 */
+        const double slope = mag[i] - r->last_sync;
+        r->last_sync = mag[i];
+        if ((slope < 0.0) && (r->last_sync_slope * slope) < 0.0) {
+            const int bit = (r->last_data >= 0) ? 1 : 0;
+            po_rds_new_bit(r, bit ^ r->last_bit);
+            r->last_bit = bit;
+        }
+        r->last_data = data[i];
+        r->last_sync_slope = slope;
+    }
+    r->n_last = len;
+    free(raw);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * WFM mono demod -- application/demod/demod_wfm.cpp
  * ---------------------------------------------------------------------------------------------- */
 void po_demod_wfm_init(po_demod_wfm *d, double fs) /* init()+setSampleRate(), demod_wfm.cpp:100-196 */
@@ -884,6 +1123,50 @@ void po_demod_wfm_init(po_demod_wfm *d, double fs) /* init()+setSampleRate(), de
     d->pll_beta = (d->pll_alpha * d->pll_alpha) / (4.0 * .707 * .707);
     d->err_ave = 0.0;
     d->err_alpha = (1.0 - exp(-1.0 / (fs * .5)));                     /* LOCK_TIMECONST .5 */
+    d->rds = (struct po_rds *)malloc(sizeof(struct po_rds));          /* :187-191 */
+    po_rds_init(d->rds, fs);
+}
+void po_demod_wfm_free(po_demod_wfm *d)
+{
+    if (!d || !d->rds) return;
+    free(d->rds->dc.work); free(d->rds->data); free(d->rds->sync); free(d->rds->bits); free(d->rds->pushed);
+    free(d->rds);
+    d->rds = NULL;
+}
+double po_demod_wfm_rds_rate(const po_demod_wfm *d) { return d->rds->rate; }
+int po_demod_wfm_rds_last(const po_demod_wfm *d, double *data, double *sync, int cap)
+{
+    const int n = d->rds->n_last < cap ? d->rds->n_last : cap;
+    if (data) memcpy(data, d->rds->data, (size_t)n * sizeof(double));
+    if (sync) memcpy(sync, d->rds->sync, (size_t)n * sizeof(double));
+    return d->rds->n_last;
+}
+int po_demod_wfm_rds_bits(po_demod_wfm *d, uint8_t *bits, int cap)
+{
+    const int n = d->rds->n_bits < cap ? d->rds->n_bits : cap;
+    if (bits) memcpy(bits, d->rds->bits, (size_t)n);
+    d->rds->n_bits = 0;
+    return n;
+}
+int po_demod_wfm_rds_pushed(po_demod_wfm *d, po_rds_group *g, int cap)
+{
+    const int n = d->rds->n_pushed < cap ? d->rds->n_pushed : cap;
+    if (g) memcpy(g, d->rds->pushed, (size_t)n * sizeof(po_rds_group));
+    d->rds->n_pushed = 0;
+    return n;
+}
+int po_demod_wfm_next_rds_group(po_demod_wfm *d, po_rds_group *g, int *changed) /* getNextRdsGroupData, :763-786 */
+{
+    struct po_rds *r = d->rds;
+    if (changed) *changed = 0;
+    if ((r->qhead == r->qtail) || !g) return 0;
+    *g = r->q[r->qtail++];
+    if (r->qtail >= PO_RDS_Q_SIZE) r->qtail = 0;
+    if ((r->last_group.a != g->a) || (r->last_group.b != g->b) || (r->last_group.c != g->c) || (r->last_group.d != g->d)) {
+        r->last_group = *g;
+        if (changed) *changed = 1;
+    }
+    return 1;
 }
 
 /* HILBLP_H, demod_wfm.cpp:79-98: 61-tap symmetric low-pass prototype (Kaiser-Bessel, 30 kHz at 250 kHz); first 31 taps */
@@ -969,6 +1252,7 @@ int po_demod_wfm_process_stereo(po_demod_wfm *d, const double *in, double *out, 
             out[2 * i] = raw[i]; out[2 * i + 1] = raw[i];
         }
     }
+    po_rds_process(d->rds, n, cpx);                     /* :296-357 */
     free(raw); free(raw2); free(cpx); free(pil); free(phase);
     /* :359-361, shared with the mono path */
     po_fir_process_cpx(&d->lp, n, out, out);
@@ -1321,6 +1605,7 @@ struct po_receiver {
     po_demod_nfm nfm;
     po_demod_sam sam;
     po_demod_wfm wfm;
+    po_rds_group *rds_polled; uint8_t *rds_changed; int n_rds, cap_rds; /* what Demod::fmStereo took from the queue, demod.cpp:207-219 */
     double *mixed, *working, *samplebuf, *bpout, *demodout;
     uint32_t samplebuf_len;
     int cond_flags; double iq_gain, iq_phase; po_iir dc; po_nb nb; po_anf anf; int anf_on;
@@ -1372,6 +1657,7 @@ void po_receiver_free(po_receiver *r)
     po_spectrum_free(r->spec); po_fastfir_free(r->bp);
     free(r->mixed); free(r->working); free(r->samplebuf); free(r->bpout); free(r->demodout);
     po_agc_free(r->agc); po_resampler_free(r->resamp); free(r->cond); free(r->last_spec);
+    po_demod_wfm_free(&r->wfm); free(r->rds_polled); free(r->rds_changed);
     free(r);
 }
 
@@ -1385,6 +1671,26 @@ int po_receiver_set_filter(po_receiver *r, double lo, double hi) /* :658-664, ba
     return rc;
 }
 double po_receiver_demod_rate(const po_receiver *r, int wfm) { return wfm ? r->wfm_rate : r->demod_rate; }
+/* Demod::fmStereo, demod.cpp:196-226: one getNextRdsGroupData per processDataStereo call */
+static void po_receiver_poll_rds(po_receiver *r)
+{
+    po_rds_group g; int changed = 0;
+    if (!po_demod_wfm_next_rds_group(&r->wfm, &g, &changed)) return;
+    if (r->n_rds == r->cap_rds) {
+        r->cap_rds = r->cap_rds ? 2 * r->cap_rds : 64;
+        r->rds_polled = (po_rds_group *)realloc(r->rds_polled, (size_t)r->cap_rds * sizeof(po_rds_group));
+        r->rds_changed = (uint8_t *)realloc(r->rds_changed, (size_t)r->cap_rds);
+    }
+    r->rds_polled[r->n_rds] = g; r->rds_changed[r->n_rds++] = (uint8_t)changed;
+}
+int po_receiver_rds_polled(po_receiver *r, po_rds_group *g, uint8_t *changed, int cap)
+{
+    const int n = r->n_rds < cap ? r->n_rds : cap;
+    if (g) memcpy(g, r->rds_polled, (size_t)n * sizeof(po_rds_group));
+    if (changed) memcpy(changed, r->rds_changed, (size_t)n);
+    r->n_rds = 0;
+    return n;
+}
 uint32_t po_receiver_dec_stages(const po_receiver *r, int wfm)
 {
     return po_decimator_dec_by2_stages(wfm ? r->dec_wfm : r->dec);
@@ -1427,11 +1733,11 @@ uint32_t po_receiver_process(po_receiver *r, const double *in, uint32_t n, doubl
         /* :896 Demod::processBlock */
         /* demod.cpp:113-122: dmFMM -> fmMono, dmFMS -> fmStereo */
         if (!r->audio_rate) {
-            if (r->mode == PO_FMS) po_demod_wfm_process_stereo(&r->wfm, r->samplebuf, audio, (int)ns);
+            if (r->mode == PO_FMS) { po_demod_wfm_process_stereo(&r->wfm, r->samplebuf, audio, (int)ns); po_receiver_poll_rds(r); }
             else po_demod_wfm_process_mono(&r->wfm, r->samplebuf, audio, (int)ns);
             return ns;
         }
-        if (r->mode == PO_FMS) po_demod_wfm_process_stereo(&r->wfm, r->samplebuf, r->demodout, (int)ns);
+        if (r->mode == PO_FMS) { po_demod_wfm_process_stereo(&r->wfm, r->samplebuf, r->demodout, (int)ns); po_receiver_poll_rds(r); }
         else po_demod_wfm_process_mono(&r->wfm, r->samplebuf, r->demodout, (int)ns);
         /* :901, :1000-1001 resampRate = m_demodWfmSampleRate / m_audioOutRate */
         return (uint32_t)po_resampler_process(r->resamp, (int)ns, ((double)r->wfm_rate * 1.0) / ((double)r->audio_rate * 1.0), r->demodout, audio);

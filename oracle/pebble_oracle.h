@@ -139,8 +139,8 @@ typedef struct {
 void po_demod_sam_init(po_demod_sam *d, double fs);
 void po_demod_sam_process(po_demod_sam *d, const double *in, double *out, int n);
 
-/* ---- Demod_WFM::processDataMono / processDataStereo (audio; the RDS branch leaves the audio untouched and is not
- * restated): application/demod/demod_wfm.cpp:154-232, 255-297, 359-362, 371-429, 451-485, 792-821 ---- */
+/* ---- Demod_WFM::processDataMono / processDataStereo (audio and the RDS branch up to the group queue; the text decoder
+ * behind it, rdsdecode.cpp, is GUI): application/demod/demod_wfm.cpp:154-232, 255-365, 371-429, 451-485, 488-821 ---- */
 typedef struct {
     double fs, d1_re, d1_im, deemph_alpha, deemph_re, deemph_im;
     po_iir mono_lp, notch;
@@ -150,8 +150,19 @@ typedef struct {
     po_iir pilot_bp;
     double nco_phase, nco_freq, nco_lo, nco_hi, pll_alpha, pll_beta, err_ave, err_alpha, phase_adjust;
     int pilot_locked;
+    struct po_rds *rds;   /* the RDS branch of processDataStereo (:296-357), allocated by init */
 } po_demod_wfm;
+typedef struct { uint16_t a, b, c, d; } po_rds_group; /* tRDS_GROUPS, rbdsconstants.h */
 void po_demod_wfm_init(po_demod_wfm *d, double fs);
+void po_demod_wfm_free(po_demod_wfm *d);              /* releases what init allocated (the RDS state) */
+/* RDS branch (demod_wfm.cpp:296-357, 488-761): rate behind m_RdsDownConvert, the matched filter's output (m_RdsData) and the bit-sync
+ * resonator's output of the LAST processDataStereo call, the bits handed to processNewRdsBit and the groups put into m_RdsGroupQueue since
+ * the last drain (a cleared queue shows as the all-zero group the reference stuffs in), and getNextRdsGroupData itself */
+double po_demod_wfm_rds_rate(const po_demod_wfm *d);
+int po_demod_wfm_rds_last(const po_demod_wfm *d, double *data, double *sync, int cap);
+int po_demod_wfm_rds_bits(po_demod_wfm *d, uint8_t *bits, int cap);
+int po_demod_wfm_rds_pushed(po_demod_wfm *d, po_rds_group *g, int cap);
+int po_demod_wfm_next_rds_group(po_demod_wfm *d, po_rds_group *g, int *changed); /* returns 0 when the queue is empty */
 /* out = (left, right); returns the pilot-lock flag of this block (m_PilotLocked) */
 int po_demod_wfm_process_stereo(po_demod_wfm *d, const double *in, double *out, int n);
 /* in is const here; the reference overwrites its input (demod_wfm.cpp:212) */
@@ -215,6 +226,9 @@ void po_receiver_set_mixer(po_receiver *r, double f);                 /* receive
 int po_receiver_set_filter(po_receiver *r, double lo, double hi);     /* receiver.cpp:658 */
 double po_receiver_demod_rate(const po_receiver *r, int wfm);
 uint32_t po_receiver_dec_stages(const po_receiver *r, int wfm);
+/* dmFMS: the groups Demod::fmStereo popped (one getNextRdsGroupData per frame, demod.cpp:207-219) since the last drain, and whether each
+ * differed from the one before it (only those reach the text decoder) */
+int po_receiver_rds_polled(po_receiver *r, po_rds_group *g, uint8_t *changed, int cap);
 /* one frame in; returns number of audio samples written (0 while accumulating, else frames_per_buffer);
  * spectrum_db (may be NULL) receives the unprocessed spectrum of this frame (every frame, no timer gate).
  * audio must hold max(frames_per_buffer, fastfir_fft) complex samples (the 8192/4097 FastFIR variant

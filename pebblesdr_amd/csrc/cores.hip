@@ -1394,6 +1394,7 @@ void WfmCore::release()
     d_hilb = nullptr;
     d_stereo_list = nullptr;
     lm.release();
+    rds.release();
     for (void *q : p) if (q) (void)hipFree(q);
     d_taps = nullptr;
     d_lp_state[0] = d_lp_state[1] = d_dn_state[0] = d_dn_state[1] = nullptr;
@@ -1421,6 +1422,10 @@ int WfmCore::set_stereo(uint32_t ch, bool on)
         memset(z.data(), 0, sizeof(WfmPilotState) * C);
         for (auto &q : z) { q.nco_freq = pd.nco_freq0; q.quiet = 1LL << 40; }
         PG_HIP(hipMemcpy(d_pilot, z.data(), sizeof(WfmPilotState) * C, hipMemcpyHostToDevice));
+        // the RDS members, initialised with the rest of setSampleRate (demod_wfm.cpp:187-191)
+        const char *e = getenv("PEBBLEGPU_RDS");
+        rds_enabled = !(e && e[0] == '0');
+        if (rds_enabled) { if (int rc = rds.init(C, rate, max_n_)) return rc; }
     }
     if (stereo[ch] != (unsigned char)on) stereo_dirty = true;
     stereo[ch] = on;
@@ -1494,6 +1499,8 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
             std::vector<TailJob> lj(1, TailJob{lm.data(), lm.pitch, n, lm.hist, 0, nullptr, 0});
             if (int rc = run_save_tails(s, lj, C)) return rc;
             PG_HIP(hipGetLastError());
+            // the RDS branch (demod_wfm.cpp:296-357) runs whether the pilot is locked or not
+            if (int rc = rds.run(s, in, in_pitch, n, (const double *)d_hilb, (const int *)d_stereo_list, n_stereo, stereo_block)) return rc;
         }
         return 0;
     }

@@ -224,6 +224,43 @@ WfmPilotDesign wfm_pilot_design(double fs)
     return d;
 }
 
+RdsDesign rds_design(double fs)
+{
+    RdsDesign d;
+    const DcChain c = downconvert_chain(fs, 8000.0, false);   // demod_wfm.cpp:187
+    d.rate = c.out_rate;
+    d.stages = c.stages;
+    d.osc_turns = 57000.0 / fs;                                // :188 with downconvert.cpp:103-108
+    d.lp = fir_lowpass(0, 1.0, 40.0, 2400.0, 1.3 * 2400.0, d.rate);  // :496
+    const double norm = kTwoPi / d.rate;
+    d.nco_lo = (0.0 - 12.0) * norm;                            // RDSPLL_RANGE, :500-501
+    d.nco_hi = (0.0 + 12.0) * norm;
+    d.alpha = 2.0 * .707 * 1.0 * norm;                         // RDSPLL_ZETA, RDSPLL_BW
+    d.beta = (d.alpha * d.alpha) / (4.0 * .707 * .707);
+    const double bitrate = 57000.0 / 48.0;
+    int len = (int)(d.rate / bitrate);                         // m_MatchCoefLength, an int (:507)
+    std::vector<double> co(2 * (size_t)len + 1, 0.0);
+    for (int i = 0; i <= len; i++) {                           // :508-517 as written: i = 0 goes through 1 / infinity
+        const double t = (double)i / d.rate, x = t * bitrate, x64 = 64.0 * x;
+        const double v = .75 * std::cos(2.0 * kTwoPi * x) * ((1.0 / (1.0 / x - x64)) - (1.0 / (9.0 / x - x64)));
+        co[(size_t)(i + len)] = v;
+        co[(size_t)(len - i)] = -v;
+    }
+    len *= 2;                                                  // :518; InitConstFir clips at MAX_NUMCOEF (fir.cpp:180-183)
+    if (len > 75) len = 75;
+    d.matched.assign(co.begin(), co.begin() + len);
+    d.bitsync = biquad_bandpass(bitrate, 500, d.rate);         // :522
+    return d;
+}
+void oscillator_amplitudes(double *tab, int n)
+{
+    double a = 1.0;
+    for (int i = 0; i < n; i++) {
+        tab[i] = a;
+        a = a * (1.95 - a * a);
+    }
+}
+
 double blackman_harris(uint32_t n, std::vector<double> &w)
 {
     // float constants and a float 2*pi, exactly as the reference declares them (windowfunction.cpp:49-51,218-222)

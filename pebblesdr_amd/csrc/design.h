@@ -70,6 +70,22 @@ struct WfmPilotDesign {
 };
 WfmPilotDesign wfm_pilot_design(double fs);
 
+// Demod_WFM's RDS members at demodulator rate fs (demod_wfm.cpp:187-191 setSampleRate, :490-537 initRds): m_RdsDownConvert's chain
+// (SetDataRate(fs, 8000); SetFrequency(-57000), whose argument CDownConvert negates: the oscillator turns at +57000 Hz), the 2400 Hz
+// low-pass behind it, the PLL's constants, the biphase matched filter and the bit-rate resonator
+struct RdsDesign {
+    double rate = 0;                 // behind the chain
+    std::vector<int> stages;         // indices into the CDownConvert stage table (downconvert_stage_response)
+    double osc_turns = 0;            // oscillator increment, turns per input sample
+    std::vector<double> lp;          // y[i] = sum_k lp[k] x[i - k]
+    std::vector<double> matched;     // y[i] = sum_k matched[k] x[i - k]: the first 2 len of the 2 len + 1 values initRds computes
+    Biquad bitsync;
+    double nco_lo = 0, nco_hi = 0, alpha = 0, beta = 0;
+};
+RdsDesign rds_design(double fs);
+// |m_Osc1| of CDownConvert's (and Mixer's) oscillator before sample n: a_0 = 1, a_{n+1} = a_n (1.95 - a_n^2) -> sqrt(0.95), in double
+void oscillator_amplitudes(double *tab, int n);
+
 // WindowFunction BLACKMANHARRIS, pebblelib/windowfunction.cpp:214-235; returns coherentGain = sum/N
 double blackman_harris(uint32_t n, std::vector<double> &w);
 

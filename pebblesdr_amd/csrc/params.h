@@ -120,6 +120,36 @@ struct WfmPilotState {
     int skip, pad_;                        // this call adds nothing to the output (set per call for the FIR behind)
 };
 
+// The RDS branch of Demod_WFM::processDataStereo (application/demod/demod_wfm.cpp:296-357, 488-757): constants of one demodulator
+// rate, the state one dmFMS channel carries and the record of a group put into m_RdsGroupQueue
+struct RdsParams {
+    double osc_turns;                      // m_RdsDownConvert's oscillator, turns per demodulator-rate sample
+    double nco_lo, nco_hi, alpha, beta;    // processRdsPll, :499-503
+    double b0, b2, a1, a2;                 // bit-rate resonator (b1 = 0), :522
+    int block;                             // RDS-rate samples per processDataStereo call of the reference
+    int mtaps;                             // matched filter
+    int log_cap;                           // entries of a channel's group log (a ring)
+    int pad_;
+};
+struct RdsEvent {
+    unsigned short a, b, c, d;             // tRDS_GROUPS; all zero: the queue was cleared (:642-647)
+    unsigned flags;                        // 1: this entry is the clear + zero group of a lost signal
+    long long frame;                       // processDataStereo call (counted from the object's first) that produced it
+};
+struct RdsState {
+    double prev_re, prev_im;               // the discriminator's previous sample
+    double nco_phase, nco_freq;
+    double w1, w2;                         // resonator
+    double last_sync, last_slope, last_data;
+    long long n0;                          // samples the down-converter's oscillator has produced
+    long long frames;                      // processDataStereo calls so far
+    unsigned long long n_events;           // groups logged so far (the log is a ring of log_cap entries)
+    unsigned in_bits;                      // m_InBitStream
+    int last_bit, bit_pos, cur_block, state, bgroup, block_errors;
+    unsigned short block[4];
+    int pad_;
+};
+
 // A stream still in the device's own sample format (DeviceInterfaceBase::normalizeIQ, pebblelib/deviceinterfacebase.cpp:648-838, done
 // in the first loads of the kernels that take it instead of a separate pass): base == nullptr: the float2 pointer is the input.
 //   fmt 0 CPX8 int8 pairs, 1 CPXU8 (v - 128), 2 CPX16, 3 CPXFLOAT, 4 WAV PCM16; order 0 IQ, 1 QI, 2 I only, 3 Q only; scale includes the gain

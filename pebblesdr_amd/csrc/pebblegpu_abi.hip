@@ -169,6 +169,13 @@ int pebblegpu_set_demod_mode(pebblegpu_receiver *h, uint32_t channel, int mode)
     return h->rx.set_mode(channel, mode);
 }
 
+int pebblegpu_receiver_rds_groups(pebblegpu_receiver *h, uint32_t channel, pebblegpu_rds_group *groups, uint8_t *changed, uint32_t cap, uint32_t *n)
+{
+    if (!h || !n) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    static_assert(sizeof(pebblegpu_rds_group) == sizeof(pg::RdsGroup), "group layout");
+    return h->rx.rds_groups(channel, reinterpret_cast<pg::RdsGroup *>(groups), changed, cap, n);
+}
+
 int pebblegpu_receiver_process(pebblegpu_receiver *h, const void *d_iq, uint64_t n_samples)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");

@@ -240,6 +240,50 @@ struct PllCore {
 };
 
 // ---- Demod_WFM mono ----
+// ---- the RDS branch of Demod_WFM::processDataStereo (demod_wfm.cpp:296-357, 488-786) for the dmFMS channels of a WfmCore ----
+// Device side (kernels_rds.h): discriminator -> Hilbert pair -> m_RdsDownConvert -> 2400 Hz low-pass -> PLL -> matched filter -> bit-rate
+// resonator, slicer, block synchroniser; every completed group goes into a per-channel log with the number of the processDataStereo
+// call (frame) it fell in.  Host side: m_RdsGroupQueue (a ring of RDS_Q_SIZE with the reference's head / tail arithmetic) replayed from
+// that log together with its consumer, Demod::fmStereo (demod.cpp:196-226: ONE getNextRdsGroupData per frame) -- groups() hands out
+// what that consumer popped, each with getNextRdsGroupData's return value (the group differs from the one before it).
+struct RdsGroup { uint16_t a, b, c, d; };
+struct RdsCore {
+    uint32_t C = 0;
+    long long cap = 0;               // demodulator-rate samples per call at most
+    bool on = false;                 // allocated (first dmFMS channel of the owner)
+    design::RdsDesign des;
+    int D = 1;                       // the chain's decimation
+    RdsParams pp{};
+    HistBuf raw, mag;                // rows of double
+    std::vector<HistBuf> st;         // rows of double2: st[j] the input of stage j, st[nst] the low-pass's input
+    double2 *d_lp = nullptr;         // [C][cap / D]
+    double *d_data = nullptr;        // [C][cap / D] m_RdsData of the last call
+    RdsState *d_state = nullptr;
+    RdsEvent *d_log = nullptr;       // [C][log_cap]
+    double *d_amp = nullptr, *d_matched = nullptr, *d_lptaps = nullptr;
+    std::vector<double *> d_taps;    // per stage, oldest sample first
+    std::vector<int> ntaps, newest;
+    long long last_len = 0;
+    struct Host {                    // m_RdsGroupQueue and its consumer
+        RdsGroup q[100];
+        int head = 0, tail = 0;
+        RdsGroup last{0, 0, 0, 0};
+        unsigned long long seen = 0; // log entries replayed
+        long long frames = 0;        // frames whose pop has been replayed
+        std::vector<RdsGroup> out;
+        std::vector<unsigned char> changed;
+        unsigned long long lost = 0; // log entries overwritten before a collect() read them
+    };
+    std::vector<Host> host;
+    int init(uint32_t channels, double demod_rate, long long max_n);
+    void release();
+    // queues the branch for the listed channels; block: demodulator-rate samples per processDataStereo call of the reference
+    int run(hipStream_t s, const float2 *in, long long in_pitch, long long n, const double *d_hilb, const int *d_list, int n_list, int block);
+    int collect(hipStream_t s, uint32_t ch);   // waits for the stream, replays the channel's new log entries
+    int groups(hipStream_t s, uint32_t ch, RdsGroup *g, unsigned char *changed, uint32_t cap_out, uint32_t *n_out);
+    int signal(hipStream_t s, uint32_t ch, double *data, uint32_t cap_out, uint32_t *n_out);  // m_RdsData of the last call
+};
+
 struct WfmCore {
     uint32_t C = 0;
     double rate = 0;
@@ -275,6 +319,8 @@ struct WfmCore {
     long long max_n_ = 0;
     int stereo_block = 2048;                  // samples per processDataStereo call in the reference (the owner's frame length)
     WfmPilotParams pilot;
+    RdsCore rds;                              // the RDS branch (PEBBLEGPU_RDS=0 leaves it out)
+    bool rds_enabled = true;
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     // more_tails / oa: the caller's other tail-refresh jobs and oscillator advance; when the single-kernel path runs it carries
@@ -422,6 +468,8 @@ public:
     int ingest_submit(uint32_t slot, uint64_t bytes);
     int process_ingested(uint32_t slot, int fmt, int order, double gain, uint64_t n);
     int set_squelch(uint32_t ch, double squelch_db);   // Receiver::squelchChanged, receiver.cpp:704-707
+    // dmFMS channels of a WFM bank: what Demod::fmStereo took from the RDS group queue since the last call (waits for queued work)
+    int rds_groups(uint32_t ch, RdsGroup *g, unsigned char *changed, uint32_t cap, uint32_t *n);
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain, const RawSrc *raw = nullptr);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();

@@ -188,6 +188,14 @@ int Receiver::enable_smeter(bool on)
     return 0;
 }
 
+int Receiver::rds_groups(uint32_t ch, RdsGroup *g, unsigned char *changed, uint32_t cap, uint32_t *n)
+{
+    if (n) *n = 0;
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (!wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "RDS groups come from the dmFMS channels of a WFM bank");
+    if (int rc = sync()) return rc;
+    return wfmc_.rds.groups(nullptr, ch, g, changed, cap, n);
+}
 int Receiver::set_squelch(uint32_t ch, double squelch_db)
 {
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u of %u", ch, C);

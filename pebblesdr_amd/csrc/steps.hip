@@ -538,6 +538,22 @@ int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const d
     *out = d->hd.data();
     return 0;
 }
+int pebblegpu_demod_rds_groups(pebblegpu_demod *d, pebblegpu_rds_group *groups, uint8_t *changed, uint32_t cap, uint32_t *n)
+{
+    if (!d || !n) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    *n = 0;
+    if (d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
+    PG_HIP(hipSetDevice(d->device));
+    return d->wfm.rds.groups(d->stream, 0, reinterpret_cast<pg::RdsGroup *>(groups), changed, cap, n);
+}
+int pebblegpu_demod_rds_signal(pebblegpu_demod *d, double *data, uint32_t cap, uint32_t *n)
+{
+    if (!d || !n) return fail(PEBBLEGPU_E_INVALID, "null argument");
+    *n = 0;
+    if (d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
+    PG_HIP(hipSetDevice(d->device));
+    return d->wfm.rds.signal(d->stream, 0, data, cap, n);
+}
 
 // ---------------- Spectrum ----------------
 int pebblegpu_spectrum_create(int device, uint32_t fft_size, double sample_rate, uint32_t samples_per_buffer, pebblegpu_spectrum **out)

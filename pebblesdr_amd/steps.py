@@ -159,6 +159,22 @@ class Demod(_Step):
             return x  # pass-through modes return `in` (demod.cpp:127-138)
         return np.ctypeslib.as_array(out, shape=(2 * len(x),)).view(np.complex128).copy()
 
+    def getNextRdsGroupData(self, cap=4096):
+        """dmFMS: the groups Demod::fmStereo's one getNextRdsGroupData per processBlock call took from the queue since the last call of
+        this method -> ((n, 4) uint16 blocks A..D, (n,) bool: the function's return value)"""
+        g = np.zeros((cap, 4), dtype=np.uint16)
+        chg = np.zeros(cap, dtype=np.uint8)
+        n = C.c_uint32(0)
+        check(self.L, self.L.pebblegpu_demod_rds_groups(self.h, g.ctypes.data_as(C.c_void_p), chg.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return g[:n.value].copy(), chg[:n.value].astype(bool)
+
+    def rdsData(self, cap=1 << 16):
+        """m_RdsData of the last processBlock call (the matched filter's output in front of the bit slicer)"""
+        d = np.zeros(cap, dtype=np.float64)
+        n = C.c_uint32(0)
+        check(self.L, self.L.pebblegpu_demod_rds_signal(self.h, d.ctypes.data_as(_dp), cap, C.byref(n)))
+        return d[:min(n.value, cap)].copy()
+
 
 class Spectrum(_Step):
     _destroy = "pebblegpu_spectrum_destroy"

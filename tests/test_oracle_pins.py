@@ -621,3 +621,66 @@ def test_downconvert_set_data_rate_flips_the_tuned_frequency(oracle_mod):
     b = O.DownConvert(); b.set_frequency(f0); b.set_data_rate(fs, 15000)     # the other order: tuned to -f0 afterwards
     yb = b.process(x)
     assert np.abs(ya[200:]).min() > 0.4 and np.abs(yb[200:]).max() < 1e-3
+
+
+# the reference's own RDS tables (application/demod/rbdsconstants.h): the generator matrix rows, the offset words and their syndromes
+_RDS_CHKWORDGEN = [0x077, 0x2E7, 0x3AF, 0x30B, 0x359, 0x370, 0x1B8, 0x0DC, 0x06E, 0x037, 0x2C7, 0x3BF, 0x303, 0x35D, 0x372, 0x1B9]
+_RDS_PARCKH = [0x2DC, 0x16E, 0x0B7, 0x287, 0x39F, 0x313, 0x355, 0x376, 0x1BB, 0x201, 0x3DC, 0x1EE, 0x0F7, 0x2A7, 0x38F, 0x31B]
+_RDS_OFFSET_SYNDROME = {"A": 0x3D8, "B": 0x3D4, "C": 0x25C, "Cp": 0x3CC, "D": 0x258}
+
+
+def test_rds_block_coding_of_the_test_signal_against_the_reference_tables():
+    """tests/rds_signal.py builds its blocks from the published generator polynomial; the reference holds the same code as tables
+    (rbdsconstants.h): CHKWORDGEN row i is the checkword of information bit i, and the syndrome checkBlock forms (the top ten
+    bits through an identity, the low sixteen through PARCKH, demod_wfm.cpp:711-721) of a block with offset word X is
+    OFFSET_SYNDROME_BLOCK_X.  Both hold for the encoder the RDS tests transmit with."""
+    from tests import rds_signal as rs
+    assert [rs.checkword(1 << (15 - i), 0) for i in range(16)] == _RDS_CHKWORDGEN
+    rng = np.random.default_rng(5)
+    for key, want in _RDS_OFFSET_SYNDROME.items():
+        for info in rng.integers(0, 65536, 50):
+            blk = (int(info) << 10) | rs.checkword(int(info), rs.OFFSET[key])
+            syn = blk >> 16
+            for i in range(16):
+                if blk & (0x8000 >> i):
+                    syn ^= _RDS_PARCKH[i]
+            assert syn == want
+
+
+@pytest.mark.parametrize("fsw", [250000, 256000, 312500])
+def test_rds_groups_of_a_multiplex_through_the_restated_decoder(oracle_mod, fsw):
+    """The RDS branch of processDataStereo (demod_wfm.cpp:296-357, 488-786) restated in the oracle, on an FM multiplex carrying 30 known
+    groups (0A / 2A / 2B).  As written the branch tunes the WRONG way -- CDownConvert::SetFrequency negates its argument
+    (downconvert.cpp:103-108), so SetFrequency(-57000) moves the multiplex up and the decoder sees the subcarrier's image through the
+    Hilbert pair's stop band -- and its PLL's phase detector (arctan2 with 2 pi where pi / 2 belongs, :792-821) pins the loop at its
+    frequency limit with a constant lead; a subcarrier 14 Hz low stands nearly still in that loop and most groups come through, one
+    on frequency turns at ~19 Hz through the detector and few do.  Pinned here: the groups the decoder queues are groups that were sent,
+    in the order sent (the all-zero group marks a cleared queue; a miscorrected block now and then); getNextRdsGroupData pops them one per call and flags repeats.
+    parity unpinned beyond the tables above: the reference holds no recorded RDS output."""
+    O = oracle_mod
+    from tests import rds_signal as rs
+    ng = 30
+    groups = rs.make_groups(ng)
+    n = int(fsw * (ng * 104 + 60) / 1187.5)
+    n -= n % 2048
+    for off, at_least in ((-14.0, 20), (0.0, 0)):
+        x = rs.fm_multiplex(groups, float(fsw), n, subcarrier_offset_hz=off)
+        d = O.DemodWFM(float(fsw))
+        assert d.rds_rate in (fsw / 8.0, fsw / 16.0)
+        pushed, popped = [], []
+        for k in range(n // 2048):
+            d.process_stereo(x[k * 2048:(k + 1) * 2048])
+            pushed += [tuple(int(v) for v in r) for r in d.rds_pushed()]
+            g = d.next_rds_group()                      # Demod::fmStereo: one per frame
+            if g is not None:
+                popped.append(g)
+        sent = [tuple(g) for g in groups]
+        real = [g for g in pushed if g != (0, 0, 0, 0)]
+        idx = [sent.index(g) for g in real if g in sent]
+        assert len(idx) >= at_least
+        assert idx == sorted(idx) and len(set(idx)) == len(idx)  # queued once, in the order sent
+        assert len(real) - len(idx) <= 3                # (the burst corrector "repairs" the odd damaged block into another valid one)
+        assert [g for g, _ in popped] == pushed[:len(popped)] or (0, 0, 0, 0) in pushed
+        assert all(ch for _, ch in popped[:1])
+        bits = d.rds_bits()
+        assert abs(len(bits) - n / fsw * 1187.5) < 30   # the resonator delivers the bit clock (a peak more or less where the signal nulls)

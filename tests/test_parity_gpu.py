@@ -309,6 +309,84 @@ def test_wfm_stereo_mode_in_the_receiver(gpu_lib, oracle_mod):
         assert np.array_equal(ga[k].real, ga[k].imag)
 
 
+@pytest.mark.parametrize("fsw", [250000, 312500])
+def test_wfm_stereo_rds_branch_against_the_oracle(gpu_lib, oracle_mod, fsw):
+    """The RDS branch of processDataStereo (demod_wfm.cpp:296-357, 488-786; tests/test_oracle_pins.py for what the reference's branch
+    does with a broadcast multiplex): m_RdsData -- the matched filter's output, behind the down-converter, the low-pass and the PLL -- of
+    every processBlock call at 1e-6 (the branch runs in double on the device as in the reference; both sides are handed the same
+    single-precision samples, the step's upload format: the wanted signal sits ~70 dB under the multiplex), and the groups
+    Demod::fmStereo's one getNextRdsGroupData per call pops, with the function's return values, bit for bit.  The audio of the same calls
+    stays at 1e-5."""
+    import pebblesdr_amd as P
+    from tests import rds_signal as rs
+    ng, blk = 24, 4096
+    groups = rs.make_groups(ng, seed=11)
+    n = int(fsw * (ng * 104 + 60) / 1187.5)
+    n -= n % blk
+    x = rs.fm_multiplex(groups, float(fsw), n, subcarrier_offset_hz=-14.0).astype(np.complex64).astype(np.complex128)
+    ref = oracle_mod.DemodWFM(float(fsw))
+    d = P.Demod(64000, fsw, blk)
+    d.setDemodMode(P.DM_FMS)
+    want = []
+    worst = 0.0
+    for k in range(n // blk):
+        fr = x[k * blk:(k + 1) * blk]
+        r, _ = ref.process_stereo(fr)
+        g = d.processBlock(fr)
+        assert rel_rms(g.real, r.real) <= TOL and rel_rms(g.imag, r.imag) <= TOL, k
+        popped = ref.next_rds_group()
+        if popped is not None:
+            want.append(popped)
+        if k % 8 == 0 or k < 4:
+            rd, gd = ref.rds_last()[0], d.rdsData()
+            assert len(rd) == len(gd) == blk * ref.rds_rate / fsw
+            worst = max(worst, rel_rms(gd, rd))
+    assert worst <= 1e-6, worst                                  # (measured 5e-8)
+    got_g, got_c = d.getNextRdsGroupData()
+    assert len(want) >= 12                                       # (most of the 24 groups come through at this subcarrier offset)
+    assert [tuple(int(v) for v in row) for row in got_g] == [g for g, _ in want]
+    assert list(got_c) == [c for _, c in want]
+    sent = [tuple(g) for g in groups]
+    assert sum(1 for g, _ in want if g in sent) >= 12
+    assert d.getNextRdsGroupData()[0].shape == (0, 4)            # drained
+
+
+def test_wfm_stereo_rds_groups_in_the_receiver(gpu_lib, oracle_mod):
+    """RDS through the whole chain: a 2.5 Msps WFM receiver in dmFMS, 16 super-frames (= frames of the demodulator) per call, against
+    the oracle's Receiver fed frame by frame: the groups Demod::fmStereo pops (one getNextRdsGroupData per demodulated frame) and
+    their changed flags.  The receive chain in front of the branch runs in single precision here and in double in the oracle: the
+    image the decoder works on (see above) keeps three digits, enough for the same bits on this input."""
+    import pebblesdr_amd as P
+    from tests import rds_signal as rs
+    fs, nf, ksf = 2_500_000, 2048, 16
+    rx = P.ReceiverBank(fs, 1, True, True, 0, max_superframes=ksf)
+    rx.set_mode(0, P.DM_FMS)
+    rx.set_mixer(0, 250e3)
+    sf = rx.superframe
+    ng = 16
+    groups = rs.make_groups(ng, seed=12)
+    n = int(fs * (ng * 104 + 60) / 1187.5)
+    n -= n % (ksf * sf)
+    x = rs.fm_multiplex(groups, float(fs), n, subcarrier_offset_hz=-14.0) * np.exp(2j * np.pi * 250e3 * np.arange(n) / fs)
+    ref = oracle_mod.Receiver(fs, nf, 0)
+    ref.set_mode(oracle_mod.FMS)
+    ref.set_mixer(250e3)
+    for f in range(n // nf):
+        ref.process(x[f * nf:(f + 1) * nf], want_spectrum=False)
+    want_g, want_c = ref.rds_polled()
+    got_g, got_c = [], []
+    for k in range(n // (ksf * sf)):
+        rx.process(x[k * ksf * sf:(k + 1) * ksf * sf])
+        if k % 3 == 2:                                           # read now and then, not after every call
+            g, c = rx.rds_groups(0)
+            got_g += [tuple(int(v) for v in r) for r in g]; got_c += list(c)
+    g, c = rx.rds_groups(0)
+    got_g += [tuple(int(v) for v in r) for r in g]; got_c += list(c)
+    assert len(want_g) >= 6
+    assert got_g == [tuple(int(v) for v in r) for r in want_g]
+    assert got_c == list(want_c)
+
+
 def test_wfm_bank_with_mono_and_stereo_channels(gpu_lib, oracle_mod):
     """dmFMM and dmFMS side by side in one WFM bank off a shared stream (the pre-filter switch is per channel)."""
     import pebblesdr_amd as P
