@@ -227,6 +227,17 @@ public:
         if (!h || (status = report("demod_process", pebblegpu_demod_process(h, reinterpret_cast<const double *>(in), bufSize, &out))) != 0) return in;
         return reinterpret_cast<CPX *>(const_cast<double *>(out));
     }
+    // int Demod_WFM::getNextRdsGroupData(tRDS_GROUPS *), demod_wfm.h:39, as Demod::fmStereo calls it (demod.cpp:207-219: once behind
+    // every processDataStereo): 0 while nothing is queued or the group repeats the one before it, else 1 with the group in *g -- the
+    // value to hand to CRdsDecode::decodeRdsGroup when BlockA != 0.  (The library has popped one group per processBlock call already;
+    // this walks that list.)
+    int getNextRdsGroupData(pebblegpu_rds_group *g)
+    {
+        uint32_t n = 0;
+        uint8_t changed = 0;
+        if (!h || !g || pebblegpu_demod_rds_groups(h, g, &changed, 1, &n) != 0 || n == 0) return 0;
+        return changed ? 1 : 0;
+    }
 
 private:
     pebblegpu_demod *h = nullptr;

@@ -341,7 +341,10 @@ def test_wfm_stereo_rds_branch_against_the_oracle(gpu_lib, oracle_mod, fsw):
             rd, gd = ref.rds_last()[0], d.rdsData()
             assert len(rd) == len(gd) == blk * ref.rds_rate / fsw
             worst = max(worst, rel_rms(gd, rd))
-    assert worst <= 1e-6, worst                                  # (measured 5e-8)
+    # measured 5e-8, in the blocks where the loop's residual rotation carries the subcarrier through the real axis: m_RdsData is the
+    # imaginary part only, there a small projection of the signal, and the 1e-10 rad by which the oscillator's closed form and the
+    # reference's recurrence have drifted apart after 5e5 samples leaks the real part into it, weighted hundreds of times
+    assert worst <= 1e-6, worst
     got_g, got_c = d.getNextRdsGroupData()
     assert len(want) >= 12                                       # (most of the 24 groups come through at this subcarrier offset)
     assert [tuple(int(v) for v in row) for row in got_g] == [g for g, _ in want]
@@ -385,6 +388,45 @@ def test_wfm_stereo_rds_groups_in_the_receiver(gpu_lib, oracle_mod):
     assert len(want_g) >= 6
     assert got_g == [tuple(int(v) for v in r) for r in want_g]
     assert got_c == list(want_c)
+
+
+def test_wfm_bank_rds_of_two_stations_in_one_stream(gpu_lib, oracle_mod):
+    """Two broadcast multiplexes in one 2.5 Msps stream, a WFM bank of three channels off it -- dmFMS on the first station, dmFMM on it
+    too, dmFMS on the second station: every dmFMS channel runs its own RDS branch (own down-converter history, PLL, block synchroniser
+    and group queue) and delivers the groups and flags the oracle's Receiver tuned the same way delivers; the mono channel has none."""
+    import pebblesdr_amd as P
+    from tests import rds_signal as rs
+    fs, nf, ksf = 2_500_000, 2048, 16
+    tune = (250e3, 250e3, -600e3)
+    modes = (P.DM_FMS, P.DM_FMM, P.DM_FMS)
+    rx = P.ReceiverBank(fs, 3, True, True, 0, max_superframes=ksf)
+    for c in range(3):
+        rx.set_mode(c, modes[c]); rx.set_mixer(c, tune[c])
+    sf = rx.superframe
+    ng = 12
+    ga, gb = rs.make_groups(ng, seed=21), rs.make_groups(ng, seed=22, pi=0x1234)
+    n = int(fs * (ng * 104 + 60) / 1187.5)
+    n -= n % (ksf * sf)
+    t = np.arange(n) / fs
+    x = rs.fm_multiplex(ga, float(fs), n, subcarrier_offset_hz=-14.0, seed=5) * np.exp(2j * np.pi * 250e3 * t) \
+        + 0.7 * rs.fm_multiplex(gb, float(fs), n, subcarrier_offset_hz=-13.0, seed=6) * np.exp(-2j * np.pi * 600e3 * t)
+    want = {}
+    for c in (0, 2):
+        ref = oracle_mod.Receiver(fs, nf, 0)
+        ref.set_mode(oracle_mod.FMS); ref.set_mixer(tune[c])
+        for f in range(n // nf):
+            ref.process(x[f * nf:(f + 1) * nf], want_spectrum=False)
+        g, ch = ref.rds_polled()
+        want[c] = ([tuple(int(v) for v in r) for r in g], list(ch))
+        assert len(g) >= 4
+    assert want[0][0] != want[2][0]
+    for k in range(n // (ksf * sf)):
+        rx.process(x[k * ksf * sf:(k + 1) * ksf * sf])
+    for c in (0, 2):
+        g, ch = rx.rds_groups(c)
+        assert [tuple(int(v) for v in r) for r in g] == want[c][0], c
+        assert list(ch) == want[c][1], c
+    assert len(rx.rds_groups(1)[0]) == 0
 
 
 def test_wfm_bank_with_mono_and_stereo_channels(gpu_lib, oracle_mod):
