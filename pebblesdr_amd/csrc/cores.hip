@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
+#include <hip/hip_ext.h>
 #include "kernels_demod.h"
 #include "kernels_fastfir.h"
 #include "kernels_frontend.h"
@@ -386,10 +387,13 @@ bool bank_variant(int np, int t1, int t2, int t3, int *hy, int *nstate, int *min
 
 template <int NP>
 static int launch_bank(void *kern, unsigned n_wg, hipStream_t s, const float2 *d_in, float2 *out, const ChanOsc *osc, const OscDynInline &dyn, const float2 *xh,
-                       float2 *xh_out, const float2 *y0h, float2 *y0s, float2 *mixed, const BankDecParams<NP> &bp)
+                       float2 *xh_out, const float2 *y0h, float2 *y0s, float2 *mixed, const BankDecParams<NP> &bp, hipEvent_t stop = nullptr)
 {
     using K = void (*)(const float2 *, float2 *, const ChanOsc *, OscDynInline, const float2 *, float2 *, const float2 *, float2 *, float2 *, BankDecParams<NP>);
-    launch(reinterpret_cast<K>(kern), dim3(n_wg), dim3(256), s, d_in, out, osc, dyn, xh, xh_out, y0h, y0s, mixed, bp);
+    // stop: an event that completes with THIS dispatch (the packet's own completion signal) -- recorded afterwards it would be a packet
+    // of its own in the queue, ~6 us of idle GPU in front of the next call's decimator
+    if (stop) hipExtLaunchKernelGGL(reinterpret_cast<K>(kern), dim3(n_wg), dim3(256), 0, s, nullptr, stop, 0, d_in, out, osc, dyn, xh, xh_out, y0h, y0s, mixed, bp);
+    else launch(reinterpret_cast<K>(kern), dim3(n_wg), dim3(256), s, d_in, out, osc, dyn, xh, xh_out, y0h, y0s, mixed, bp);
     PG_HIP(hipGetLastError());
     return 0;
 }
@@ -505,7 +509,7 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
         if (dbg && bv->t1 == 19 && bv->t2 == 27 && bv->t3 == 59)
             kern = dbg == 1 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 1> : dbg == 2 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 2> : dbg == 4 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 4>
                  : dbg == 8 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 8> : dbg == 16 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 16> : dbg == 31 ? (void *)k_mix_dec_mfma<4, 19, 27, 59, 31> : kern;
-        if (int rc = launch_bank<4>(kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp)) return rc;
+        if (int rc = launch_bank<4>(kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp, done_event)) return rc;
     } else {
         // CIC3 at stride S0 in the reference's merged form (decimator.cpp:719-737: output k = .125 (od_k + ev_{k-1} + 3 (od_{k-1} + ev_k)) of the
         // sample pairs (ev, od)_P = x[S0 P], x[S0 P + 1]) under the hb11 at stride 16: relative to sample S j, pair q = -11 .. 0 carries
@@ -524,8 +528,9 @@ int DecimCore::run_bank_mfma(hipStream_t s, const float2 *d_in, long long n, con
             bp.oa[2 * i + 1] = S0 * (-11 - q);  bp.ob[2 * i + 1] = S0 * q + 1;  bp.g[2 * i + 1] = (h(q + 10) + 3.f * h(q + 11)) * 0.125f;
         }
         for (int p = 0; p < 12; p++) bp.e[p] = 0.5f * (float)(bp.oa[p] - bp.ob[p]);
-        if (int rc = launch_bank<12>(bv->kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp)) return rc;
+        if (int rc = launch_bank<12>(bv->kern, n_wg, s, d_in, fin.data(), (const ChanOsc *)osc.d_osc, osc.inline_dyn, xh, xh_out, y0_hist, d_y0stage2[y0_cur ^ 1], mixed, bp, done_event)) return rc;
     }
+    done_recorded = done_event != nullptr;
     if (want_clk) {
         std::vector<unsigned long long> h((size_t)n_wg * 16);
         PG_HIP(hipStreamSynchronize(s));
@@ -759,6 +764,7 @@ void DecimCore::release()
     buf1.release();
     fin.release();
     fin2.release();
+    fin3.release();
     if (d_wide_taps) (void)hipFree(d_wide_taps);
     d_wide_taps = nullptr;
     for (int i = 0; i < 2; i++) {
@@ -882,11 +888,14 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
     if (n <= 0 || n % (long long)chain.total != 0)
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
-    if (fin2.base) std::swap(fin, fin2);  // alternate calls write alternate output buffers (tail_job_out carries the look-back across)
+    // successive calls write successive output buffers (tail_job_out carries the consumer's look-back into the next one's head-room)
+    if (fin3.base) { std::swap(fin, fin2); std::swap(fin2, fin3); }  // (fin, fin2, fin3) <- (fin2, fin3, fin)
+    else if (fin2.base) std::swap(fin, fin2);
     const HistBuf *src = &buf0;
     last_fused = false;
     last_mfma = false;
     osc_advanced = false;
+    done_recorded = false;
     const bool had_bank_state = bank_state_valid;
     bank_state_valid = false;  // (set again below when this call takes the matrix-pipe route)
     const bool had_dyn = dyn_valid;
@@ -1048,7 +1057,10 @@ int DecimCore::enable_double_out()
 {
     if (casc.nst == 0 || !fin.base) return fail(PEBBLEGPU_E_UNSUPPORTED, "a single-stage chain has no separate output buffer to double");
     if (fin2.base) return 0;
-    return fin2.alloc(fin.chans, fin.hist, fin.cap);
+    if (int rc = fin2.alloc(fin.chans, fin.hist, fin.cap)) return rc;
+    const char *e = getenv("PEBBLEGPU_BANK_PIPE_BUFS");  // 2: the decimator waits for the consumer of the call before the last
+    if (e && e[0] == '2') return 0;
+    return fin3.alloc(fin.chans, fin.hist, fin.cap);
 }
 
 int fill_tail_jobs(TailJobs &tj, const std::vector<TailJob> &jobs, const OscAdvance *oa)

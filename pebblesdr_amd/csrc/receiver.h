@@ -177,7 +177,10 @@ struct DecimCore {
     // Two output buffers, written by alternate calls, so that whatever reads a call's output (the band-pass) may run on another stream
     // beside the NEXT call's decimator: the consumer's look-back (the head-room) is carried from the buffer just written into the other
     // one's head-room.  tail_jobs() = tail_jobs_dec() (the decimator's own histories: its stream) + tail_job_out() (the consumer's stream)
-    HistBuf fin2;
+    hipEvent_t done_event = nullptr;         // set by the caller before run(): an event to complete WITH the call's last launch when that is the bank kernel ...
+    bool done_recorded = false;              // ... and whether run() did so (else the caller records it)
+    HistBuf fin2, fin3;                      // fin: this call's; fin2: the next call's (its head-room filled by this call's consumer); fin3: a third, written by the call after that,
+                                             // so that a call's decimator waits for the consumer of the call THREE back (long over) instead of two (often still running)
     int enable_double_out();                 // after init(); fails for a single-stage chain (its output is the first stage's buffer)
     bool double_out() const { return fin2.base != nullptr; }
     void tail_jobs_dec(std::vector<TailJob> &jobs) const;
@@ -533,7 +536,7 @@ private:
     bool pipeline_ = false;           // successive side-by-side calls overlap (PEBBLEGPU_PIPELINE=1 when the receiver is created)
     bool touched_ = true;             // a setter ran since the last call
     bool bank_pipe_ok_ = false;       // no display transform: the call's two stages (decimator | band-pass .. resampler) on the two streams, stage 2 beside the next call's stage 1
-    hipEvent_t f_end_[2] = {nullptr, nullptr};  // where stage 2 of the last and of the last-but-one such call ended
+    hipEvent_t f_end_[3] = {nullptr, nullptr, nullptr};  // where stage 2 of the last three such calls ended
     hipEvent_t d_end_prev_ = nullptr;           // where the last call ended, if that was a two-stage call (the next one is timed from there)
     hipEvent_t sync_ev_[4] = {nullptr, nullptr, nullptr, nullptr};  // stage 1 -> stage 2 hand-over events (no timing), a ring
     hipEvent_t pipe_ev_ = nullptr;

@@ -430,8 +430,17 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (side) {
         PG_HIP(hipStreamWaitEvent(chain_stream_, start, 0));  // fork: the input is ready where the call starts
     }
-    // the output buffer this call writes was read two calls ago (a wait is a queue packet: none when the host can see that it is over)
-    if (bank_pipe && f_end_[1] && hipEventQuery(f_end_[1]) != hipSuccess) PG_HIP(hipStreamWaitEvent(stream_, f_end_[1], 0));
+    // the output buffer this call writes was read three (two) calls ago (a wait is a queue packet: none when the host can see that it is over)
+    {
+        hipEvent_t last_reader = dec_.fin3.base ? f_end_[2] : f_end_[1];  // (three output buffers: the call three back read the one this call writes)
+        if (bank_pipe && last_reader && hipEventQuery(last_reader) != hipSuccess) {
+            // the host is more than two calls ahead of the device: it waits here (PEBBLEGPU_BANK_PIPE_HOSTWAIT=0: a wait in the queue instead,
+            // one more packet between this decimator and the last)
+            static const bool host_wait = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_HOSTWAIT"); return !(e && e[0] == '0'); }();
+            if (host_wait) PG_HIP(hipEventSynchronize(last_reader));
+            else PG_HIP(hipStreamWaitEvent(stream_, last_reader, 0));
+        }
+    }
     // From here on a failing step leaves kernels queued (on the chain stream too) and histories half advanced: whatever the
     // exit, join the two streams so later work is ordered behind what was queued, and refuse further calls on the handle.
     struct Guard {
@@ -486,7 +495,14 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             if (int rc = osc_.advance_job(cs, n, &oa_pre)) return rc;
             have_oa = true;
         }
+        static const bool ext_ev = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_EXTEV"); return e && e[0] == '1'; }();  // opt-in: measured 0.0695 / 0.0753 ms (configs[2] / configs[3] shard) against 0.0663 / 0.0774 without
+        dec_.done_event = nullptr;
+        if (bank_pipe && ext_ev) {  // the hand-over event of a two-stage call: completed by the bank kernel's own dispatch when that ends the first stage
+            if (!sync_ev_[0]) for (hipEvent_t &e : sync_ev_) PG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            dec_.done_event = sync_ev_[tm.calls % 4];
+        }
         if (int rc = dec_.run(cs, d_iq, in_pitch, shared_input, (long long)n, osc_, profile_detail ? ev[2] : nullptr, raw, have_oa ? &oa_pre : nullptr)) return rc;
+        dec_.done_event = nullptr;
         if (have_oa && dec_.osc_advanced) memset(&oa_pre, 0, sizeof(oa_pre));
     }
     if (profile_detail) PG_HIP(hipEventRecord(ev[3], cs));
@@ -494,17 +510,19 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         // the decimator's own histories and the oscillators' phases stay on its stream; the rest of the call moves over
         std::vector<TailJob> jobs;
         dec_.tail_jobs_dec(jobs);
+        const bool nothing_behind = jobs.empty() && oa_pre.osc == nullptr;
         if (int rc = run_save_tails(stream_, jobs, C, &oa_pre)) return rc;  // (no launch at all behind the bank kernel: nothing left to do)
         // (an event without timing for the hand-over: PEBBLEGPU_BANK_PIPE_TIMED_EV=1 records the call's timing event instead -- A/B)
         static const bool timed_ev = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_TIMED_EV"); return e && e[0] == '1'; }();
         if (!sync_ev_[0]) for (hipEvent_t &e : sync_ev_) PG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         pipe_ev_ = timed_ev ? ev[1] : sync_ev_[tm.calls % 4];
-        PG_HIP(hipEventRecord(pipe_ev_, stream_));
+        if (!(dec_.done_recorded && nothing_behind && !timed_ev)) PG_HIP(hipEventRecord(pipe_ev_, stream_));
         cs = chain_stream_;
         PG_HIP(hipStreamWaitEvent(cs, pipe_ev_, 0));
-        // (the next call's decimator becomes ready with the same event: a short nap lets its one-wave-per-SIMD workgroups be placed before
-        // the band-pass fills the CUs -- placed behind them it ran 112 us instead of 65)
-        static const unsigned nap = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_NAP_US"); return (unsigned)(100.0 * (e ? atof(e) : 8.0)); }();
+        // (with two output buffers the next call's decimator becomes ready with the same event as this band-pass: a short nap lets its
+        // one-wave-per-SIMD workgroups be placed before the band-pass fills the CUs -- placed behind them it ran 112 us instead of 65.
+        // With three the next decimator is already running when this point is reached: no nap)
+        static const unsigned nap = [this] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_NAP_US"); return (unsigned)(100.0 * (e ? atof(e) : (dec_.fin3.base ? 0.0 : 8.0))); }();
         if (int rc = run_nap(cs, nap)) return rc;
     }
     const long long nd = dec_.out_len();
@@ -602,6 +620,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipEventRecord(ev[6], cs));
         chain_end_ = ev[6];   // for whoever needs both stages over: sync(), a call after a setter, a call of another shape
         spec_end_ = pipe_ev_;
+        f_end_[2] = f_end_[1];
         f_end_[1] = f_end_[0];
         f_end_[0] = ev[6];
         d_end_prev_ = ev[6];
