@@ -167,6 +167,10 @@ typedef struct pebblegpu_rds_group { uint16_t block_a, block_b, block_c, block_d
  * Waits for the receiver's queued work.  *n: entries written (<= cap; the rest stays for the next call). */
 int pebblegpu_receiver_rds_groups(pebblegpu_receiver *rx, uint32_t channel, pebblegpu_rds_group *groups, uint8_t *changed, uint32_t cap,
                                   uint32_t *n);
+/* int Demod_WFM::getStereoLock(int *pPilotLock), demod_wfm.h:40 (demod_wfm.cpp:436-447): *pilot_lock = m_PilotLocked after the last
+ * frame of the channel (0 before its first dmFMS frame), *changed != 0 when that differs from what the previous call of this function
+ * reported (the first call reports a change: m_LastPilotLocked starts as the opposite).  Waits for the receiver's queued work. */
+int pebblegpu_receiver_stereo_lock(pebblegpu_receiver *rx, uint32_t channel, int *pilot_lock, int *changed);
 /* AGC::setAgcMode(mode, threshold) (application/agc.cpp:53-82; Receiver::agcModeChanged/agcThresholdChanged).
  * agc_mode: the reference's AgcMode values.  With PEBBLEGPU_AGC_OFF the threshold is a manual gain slider in dB
  * (amplitude 10^((threshold/5)/20), integer division as written, agc.cpp:239-246; the constructor's OFF/1 is unit
@@ -390,6 +394,7 @@ int pebblegpu_demod_process(pebblegpu_demod *d, const double *in, int n, const d
  * slicer reads, demod_wfm.cpp:309) of the last processBlock call: *n its length, at most cap values copied */
 int pebblegpu_demod_rds_groups(pebblegpu_demod *d, pebblegpu_rds_group *groups, uint8_t *changed, uint32_t cap, uint32_t *n);
 int pebblegpu_demod_rds_signal(pebblegpu_demod *d, double *data, uint32_t cap, uint32_t *n);
+int pebblegpu_demod_stereo_lock(pebblegpu_demod *d, int *pilot_lock, int *changed);  /* getStereoLock, as above */
 
 typedef struct pebblegpu_spectrum pebblegpu_spectrum;
 /* FFT::factory + fftParams(fftSize, 0, sampleRate, samplesPerBuffer, BLACKMANHARRIS), fft.cpp:45-118 */

@@ -231,6 +231,13 @@ public:
     // every processDataStereo): 0 while nothing is queued or the group repeats the one before it, else 1 with the group in *g -- the
     // value to hand to CRdsDecode::decodeRdsGroup when BlockA != 0.  (The library has popped one group per processBlock call already;
     // this walks that list.)
+    int getStereoLock(int *pPilotLock)  // Demod_WFM::getStereoLock, demod_wfm.h:40
+    {
+        int lock = 0, changed = 0;
+        if (!h || pebblegpu_demod_stereo_lock(h, &lock, &changed) != 0) return 0;
+        if (pPilotLock) *pPilotLock = lock;
+        return changed;
+    }
     int getNextRdsGroupData(pebblegpu_rds_group *g)
     {
         uint32_t n = 0;

@@ -15,7 +15,7 @@ SYMBOLS = [
     "pebblegpu_malloc", "pebblegpu_free", "pebblegpu_memcpy_h2d", "pebblegpu_memcpy_d2h", "pebblegpu_memset",
     "pebblegpu_device_synchronize", "pebblegpu_probe_copy_gbps", "pebblegpu_normalize_iq",
     "pebblegpu_receiver_create", "pebblegpu_receiver_destroy", "pebblegpu_receiver_info",
-    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_receiver_rds_groups", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch", "pebblegpu_receiver_process_raw",
+    "pebblegpu_set_mixer_freq", "pebblegpu_set_bandpass", "pebblegpu_set_demod_mode", "pebblegpu_receiver_rds_groups", "pebblegpu_receiver_stereo_lock", "pebblegpu_set_agc", "pebblegpu_set_conditioners", "pebblegpu_set_noise_filter", "pebblegpu_set_squelch", "pebblegpu_receiver_process_raw",
     "pebblegpu_receiver_process", "pebblegpu_receiver_audio", "pebblegpu_receiver_spectrum", "pebblegpu_receiver_zoom_spectrum",
     "pebblegpu_receiver_ingest_acquire", "pebblegpu_receiver_ingest_submit", "pebblegpu_receiver_process_ingested", "pebblegpu_receiver_last_ms", "pebblegpu_receiver_kernel_name", "pebblegpu_receiver_mean_ms", "pebblegpu_receiver_set_profiling", "pebblegpu_receiver_enable_signal_strength", "pebblegpu_receiver_signal_strength", "pebblegpu_receiver_synchronize", "pebblegpu_process_iq",
     "pebblegpu_streambank_create", "pebblegpu_streambank_destroy", "pebblegpu_streambank_set_bandpass",
@@ -29,7 +29,7 @@ SYMBOLS = [
     "pebblegpu_downconvert_synchronize",
     "pebblegpu_fastfir_create", "pebblegpu_fastfir_destroy", "pebblegpu_fastfir_setup", "pebblegpu_fastfir_process",
     "pebblegpu_demod_create", "pebblegpu_demod_destroy", "pebblegpu_demod_set_mode", "pebblegpu_demod_set_bandwidth",
-    "pebblegpu_demod_process", "pebblegpu_demod_rds_groups", "pebblegpu_demod_rds_signal",
+    "pebblegpu_demod_process", "pebblegpu_demod_rds_groups", "pebblegpu_demod_rds_signal", "pebblegpu_demod_stereo_lock",
     "pebblegpu_spectrum_create", "pebblegpu_spectrum_destroy", "pebblegpu_spectrum_bins", "pebblegpu_spectrum_process",
 ]
 
@@ -157,6 +157,8 @@ def _declare(L):
     L.pebblegpu_demod_process.argtypes = [vp, dp, i32, C.POINTER(dp)]
     L.pebblegpu_demod_rds_groups.argtypes = [vp, vp, vp, u32, C.POINTER(u32)]
     L.pebblegpu_demod_rds_signal.argtypes = [vp, dp, u32, C.POINTER(u32)]
+    L.pebblegpu_demod_stereo_lock.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.pebblegpu_receiver_stereo_lock.argtypes = [vp, u32, C.POINTER(i32), C.POINTER(i32)]
     L.pebblegpu_receiver_rds_groups.argtypes = [vp, u32, vp, vp, u32, C.POINTER(u32)]
     L.pebblegpu_spectrum_create.argtypes = [i32, u32, dbl, u32, C.POINTER(vp)]
     L.pebblegpu_spectrum_destroy.argtypes = [vp]
@@ -312,6 +314,12 @@ class ReceiverBank:
 
     def set_mode(self, ch, mode):
         check(self.L, self.L.pebblegpu_set_demod_mode(self.h, ch, int(mode)))
+
+    def stereo_lock(self, ch):
+        """Demod_WFM::getStereoLock of a dmFMS channel -> (pilot lock of the last frame, changed since the last call)"""
+        lk, chg = C.c_int32(0), C.c_int32(0)
+        check(self.L, self.L.pebblegpu_receiver_stereo_lock(self.h, ch, C.byref(lk), C.byref(chg)))
+        return bool(lk.value), bool(chg.value)
 
     def rds_groups(self, ch, cap=4096):
         """dmFMS channel of a WFM bank: what Demod::fmStereo popped from the RDS group queue since the last call ->

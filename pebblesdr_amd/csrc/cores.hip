@@ -1443,6 +1443,22 @@ int WfmCore::set_stereo(uint32_t ch, bool on)
     stereo[ch] = on;
     return 0;
 }
+int WfmCore::stereo_lock(hipStream_t s, uint32_t ch, int *lock, int *changed)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (last_lock.size() != C) { last_lock.assign(C, 1); stereo_ran.assign(C, 0); }
+    int now = 0;
+    if (d_pilot && stereo_ran[ch]) {  // a block of processDataStereo has run: locked until the first block that ended without lock
+        WfmPilotState st;
+        PG_HIP(hipStreamSynchronize(s));
+        PG_HIP(hipMemcpy(&st, d_pilot + ch, sizeof(st), hipMemcpyDeviceToHost));
+        now = st.dropped ? 0 : 1;
+    }
+    if (lock) *lock = now;
+    if (changed) *changed = now != last_lock[ch] ? 1 : 0;
+    last_lock[ch] = (char)now;
+    return 0;
+}
 int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n,
                  const std::vector<TailJob> *more_tails, const OscAdvance *oa, bool *carried)
 {
@@ -1499,6 +1515,8 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         }
         parity ^= 1;
         if (n_stereo) {
+            if (last_lock.size() != C) { last_lock.assign(C, 1); stereo_ran.assign(C, 0); }
+            for (uint32_t ch = 0; ch < C; ch++) if (stereo[ch]) stereo_ran[ch] = 1;
             // dmFMS before the pilot PLL's drop-out: the (L - R) part of the blocks that end locked, through the same audio response
             if (n > lm.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
             PG_HIP(hipMemset2DAsync(lm.data(), sizeof(float2) * (size_t)lm.pitch, 0, sizeof(float2) * (size_t)n, C, s));

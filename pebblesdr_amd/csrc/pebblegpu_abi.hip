@@ -176,6 +176,12 @@ int pebblegpu_receiver_rds_groups(pebblegpu_receiver *h, uint32_t channel, pebbl
     return h->rx.rds_groups(channel, reinterpret_cast<pg::RdsGroup *>(groups), changed, cap, n);
 }
 
+int pebblegpu_receiver_stereo_lock(pebblegpu_receiver *h, uint32_t channel, int *pilot_lock, int *changed)
+{
+    if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    return h->rx.stereo_lock(channel, pilot_lock, changed);
+}
+
 int pebblegpu_receiver_process(pebblegpu_receiver *h, const void *d_iq, uint64_t n_samples)
 {
     if (!h) return fail(PEBBLEGPU_E_INVALID, "null handle");

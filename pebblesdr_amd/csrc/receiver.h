@@ -323,6 +323,10 @@ struct WfmCore {
     int stereo_block = 2048;                  // samples per processDataStereo call in the reference (the owner's frame length)
     WfmPilotParams pilot;
     RdsCore rds;                              // the RDS branch (PEBBLEGPU_RDS=0 leaves it out)
+    // Demod_WFM::getStereoLock (demod_wfm.cpp:436-447): m_PilotLocked after the last block, and whether it differs from the value the
+    // previous call of this function saw (m_LastPilotLocked starts as the opposite of m_PilotLocked: the first call reports a change)
+    std::vector<char> stereo_ran, last_lock;
+    int stereo_lock(hipStream_t s, uint32_t ch, int *lock, int *changed);
     bool rds_enabled = true;
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
@@ -473,6 +477,7 @@ public:
     int set_squelch(uint32_t ch, double squelch_db);   // Receiver::squelchChanged, receiver.cpp:704-707
     // dmFMS channels of a WFM bank: what Demod::fmStereo took from the RDS group queue since the last call (waits for queued work)
     int rds_groups(uint32_t ch, RdsGroup *g, unsigned char *changed, uint32_t cap, uint32_t *n);
+    int stereo_lock(uint32_t ch, int *lock, int *changed);
     int process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool with_chain, const RawSrc *raw = nullptr);
     int process_iq(const double *iq, uint16_t n, double *audio, uint32_t *n_audio, double *spectrum_db);
     int sync();

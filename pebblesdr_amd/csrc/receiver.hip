@@ -196,6 +196,13 @@ int Receiver::rds_groups(uint32_t ch, RdsGroup *g, unsigned char *changed, uint3
     if (int rc = sync()) return rc;
     return wfmc_.rds.groups(nullptr, ch, g, changed, cap, n);
 }
+int Receiver::stereo_lock(uint32_t ch, int *lock, int *changed)
+{
+    if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u out of range", ch);
+    if (!wfm) return fail(PEBBLEGPU_E_UNSUPPORTED, "the stereo lock belongs to the dmFMS channels of a WFM bank");
+    if (int rc = sync()) return rc;
+    return wfmc_.stereo_lock(nullptr, ch, lock, changed);
+}
 int Receiver::set_squelch(uint32_t ch, double squelch_db)
 {
     if (ch >= C) return fail(PEBBLEGPU_E_INVALID, "channel %u of %u", ch, C);

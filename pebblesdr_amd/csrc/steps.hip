@@ -546,6 +546,13 @@ int pebblegpu_demod_rds_groups(pebblegpu_demod *d, pebblegpu_rds_group *groups, 
     PG_HIP(hipSetDevice(d->device));
     return d->wfm.rds.groups(d->stream, 0, reinterpret_cast<pg::RdsGroup *>(groups), changed, cap, n);
 }
+int pebblegpu_demod_stereo_lock(pebblegpu_demod *d, int *pilot_lock, int *changed)
+{
+    if (!d) return fail(PEBBLEGPU_E_INVALID, "null handle");
+    if (d->wfm.C == 0) return fail(PEBBLEGPU_E_INVALID, "created without a WFM sample rate");
+    PG_HIP(hipSetDevice(d->device));
+    return d->wfm.stereo_lock(d->stream, 0, pilot_lock, changed);
+}
 int pebblegpu_demod_rds_signal(pebblegpu_demod *d, double *data, uint32_t cap, uint32_t *n)
 {
     if (!d || !n) return fail(PEBBLEGPU_E_INVALID, "null argument");

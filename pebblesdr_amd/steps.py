@@ -168,6 +168,12 @@ class Demod(_Step):
         check(self.L, self.L.pebblegpu_demod_rds_groups(self.h, g.ctypes.data_as(C.c_void_p), chg.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
         return g[:n.value].copy(), chg[:n.value].astype(bool)
 
+    def getStereoLock(self):
+        """Demod_WFM::getStereoLock -> (m_PilotLocked after the last processBlock call, changed since the last call of this method)"""
+        lk, chg = C.c_int32(0), C.c_int32(0)
+        check(self.L, self.L.pebblegpu_demod_stereo_lock(self.h, C.byref(lk), C.byref(chg)))
+        return bool(lk.value), bool(chg.value)
+
     def rdsData(self, cap=1 << 16):
         """m_RdsData of the last processBlock call (the matched filter's output in front of the bit slicer)"""
         d = np.zeros(cap, dtype=np.float64)

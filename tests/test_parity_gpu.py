@@ -257,6 +257,8 @@ def test_wfm_stereo_mode_is_the_reference_from_the_first_block(gpu_lib, oracle_m
         g = d.processBlock(fr)
         locks.append(lk)
         assert rel_rms(g.real, r.real) <= TOL and rel_rms(g.imag, r.imag) <= TOL, (k, locks)
+        got_lock, got_changed = d.getStereoLock()           # Demod_WFM::getStereoLock: the block's lock flag, and whether it changed
+        assert got_lock == lk and got_changed == (lk != (locks[-2] if k else True)), (k, locks)
         if lk:
             assert not np.array_equal(r.real, r.imag)  # a demultiplexed block: the channels differ
         if k >= 4:
