@@ -1139,6 +1139,15 @@ int FastFirCore::design(hipStream_t s, uint32_t ch, double lo, double hi, double
     PG_HIP(hipStreamSynchronize(s));
     return 0;
 }
+// k_fastfir_t128's grid: one-dimensional with the XCD-aware order (kernels_fastfir.h) unless PEBBLEGPU_FF_XCD=0 asks for (block, channel)
+struct FfGrid { dim3 grid; int nb, nchan; };
+static FfGrid ff_grid(long long nb, uint32_t channels)
+{
+    static const bool xcd = [] { const char *e = getenv("PEBBLEGPU_FF_XCD"); return !(e && e[0] == '0'); }();
+    const long long total = nb * (long long)channels;
+    if (!xcd || total >= (1LL << 31) - 8) return FfGrid{dim3((unsigned)nb, channels), (int)nb, 0};
+    return FfGrid{dim3((unsigned)(8 * ((total + 7) / 8))), (int)nb, (int)channels};
+}
 int FastFirCore::run(hipStream_t s, const HistBuf &in, long long n, float2 *out, long long out_pitch)
 {
     const int overlap = (int)taps - 1;
@@ -1149,8 +1158,9 @@ int FastFirCore::run(hipStream_t s, const HistBuf &in, long long n, float2 *out,
     // (twiddles from the workgroup's LDS copy here: beside a bank's decimator -- two-stage calls -- the variant that reads them through the
     // vector cache measured 0.0833 ms per configs[2] call against 0.0820; alone, in the stream bank, it is the faster one: run_ext)
     static const bool tw_lds = [] { const char *e = getenv("PEBBLEGPU_FF_TWLDS"); return !(e && e[0] == '0'); }();
-    if (fft_n == 2048 && !tw_lds) launch(k_fastfir_t128<false>, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr);
-    else if (fft_n == 2048) launch(k_fastfir_t128<true>, grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr);
+    const FfGrid fg = ff_grid(n / L, C);
+    if (fft_n == 2048 && !tw_lds) launch(k_fastfir_t128<false>, fg.grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr, fg.nb, fg.nchan);
+    else if (fft_n == 2048) launch(k_fastfir_t128<true>, fg.grid, dim3(128), s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, no_tail, (float2 *)nullptr, fg.nb, fg.nchan);
     else if (fft_n == 4096) launch(k_fastfir<4096>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     else launch(k_fastfir<8192>, grid, block, s, (const float2 *)in.data(), in.pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw, overlap, no_tail);
     PG_HIP(hipGetLastError());
@@ -1170,8 +1180,9 @@ int FastFirCore::run_ext(hipStream_t s, const float2 *in, long long in_pitch, fl
         // twiddles through the vector cache: without the 4.5 KB copy per workgroup eight workgroups fit a CU's LDS instead of six -- configs[4]'s
         // band-pass 0.222 / 0.227 -> 0.215 / 0.211 ms in alternating runs (PEBBLEGPU_FF_TWLDS=1 brings the copy back)
         static const bool twg = [] { const char *e = getenv("PEBBLEGPU_FF_TWLDS"); return !(e && e[0] == '1'); }();
-        if (twg) launch_lds(k_fastfir_t128<false>, grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
-        else launch_lds(k_fastfir_t128<true>, grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next);
+        const FfGrid fg = ff_grid(n / L, C);
+        if (twg) launch_lds(k_fastfir_t128<false>, fg.grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next, fg.nb, fg.nchan);
+        else launch_lds(k_fastfir_t128<true>, fg.grid, dim3(128), pad, s, in, in_pitch, out, out_pitch, (const float2 *)d_H, (const float2 *)d_tw128, overlap, tail, d_tail_next, fg.nb, fg.nchan);
         if (d_tail_next) {  // the kernel's last block has written the next call's overlap into the caller's other buffer
             PG_HIP(hipGetLastError());
             return 0;

@@ -62,15 +62,33 @@ static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__res
                                                              float2 *__restrict__ out, long long out_pitch,
                                                              const float2 *__restrict__ H, const float2 *__restrict__ tw128,
                                                              int overlap /* taps-1 */, const float2 *__restrict__ tail,
-                                                             float2 *__restrict__ tail_out /* or null: [c][overlap] receives the call's last `overlap` input samples */)
+                                                             float2 *__restrict__ tail_out /* or null: [c][overlap] receives the call's last `overlap` input samples */,
+                                                             int nb, int nchan)
 {
     constexpr int N = 2048, E = 16;
     __shared__ float2 lds[FftLds<N>::kSlots];
     __shared__ float2 tw_lds_[TWLDS ? kTw128Count : 1];
     const float2 *tw_lds = TWLDS ? tw_lds_ : tw128;  // (A/B: the twiddle table read through the vector cache instead of a copy per workgroup)
-    const int t = threadIdx.x, c = blockIdx.y;
+    const int t = threadIdx.x;
     const int L = N - overlap;
-    const long long b = blockIdx.x;
+    // Workgroup -> (block, channel).  A block's window repeats the `overlap` samples in front of it, which are the previous block's new
+    // samples, and every block of a channel reads the channel's 16 KiB of H: with (block, channel) = (blockIdx.x, blockIdx.y) consecutive
+    // blocks go to consecutive XCDs -- eight separate L2s -- and both come from HBM again.  nchan > 0 (a one-dimensional grid): the
+    // workgroup id's low three bits are the XCD; each XCD walks ITS eighth of the blocks in (channel, block) order, so a block's neighbour
+    // and its H are in the same L2 a moment before it.
+    int c;
+    long long b;
+    if (nchan > 0) {
+        const long long total = (long long)nb * nchan, per = (total + 7) >> 3;
+        const long long q = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((long long)(blockIdx.x >> 3) >= per || q >= total) return;  // (uniform: the whole workgroup)
+        c = (int)(q / nb);
+        b = q - (long long)c * nb;
+    } else {
+        c = blockIdx.y;
+        b = blockIdx.x;
+        nb = (int)gridDim.x;
+    }
     const float2 *x = in + (long long)c * in_pitch + b * L - overlap;  // first sample of [overlap | new]
     const float2 *h = H + (long long)c * N;
     if (TWLDS) for (int i = t; i < kTw128Count; i += 128) tw_lds_[i] = tw128[i];
@@ -86,7 +104,7 @@ static __global__ __launch_bounds__(128) void k_fastfir_t128(const float2 *__res
 #pragma unroll
         for (int m = 0; m < E; m++) v[m] = x[t + 128 * m];
     }
-    if (tail_out != nullptr && b == (long long)gridDim.x - 1) {
+    if (tail_out != nullptr && b == (long long)nb - 1) {
         // m_pFFTOverlapBuf for the next call (fastfir.cpp:312-316): the last block's window ends with them.  A different buffer
         // from `tail`, which block 0 of this launch may still be reading
         float2 *to = tail_out + (long long)c * overlap;
