@@ -1486,6 +1486,7 @@ int WfmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *ou
         PG_HIP(hipStreamSynchronize(s));
         stereo_dirty = false;
     }
+    if (n_stereo) { if (int rc = rds.check(n, stereo_block)) return rc; }  // (before anything of the call is queued)
     if (fused) {
         WfmFirParams wp;
         memset(&wp, 0, sizeof(wp));

@@ -81,9 +81,9 @@ void RdsCore::release()
     on = false;
 }
 
-int RdsCore::run(hipStream_t s, const float2 *in, long long in_pitch, long long n, const double *d_hilb, const int *d_list, int n_list, int block)
+int RdsCore::check(long long n, int block) const
 {
-    if (!on || n_list == 0) return 0;
+    if (!on) return 0;
     const size_t nst = des.stages.size();
     if (block <= 0) block = (int)n;
     if (n > cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
@@ -92,6 +92,15 @@ int RdsCore::run(hipStream_t s, const float2 *in, long long in_pitch, long long 
     for (size_t j = 0; j < nst; j++)
         if ((block >> j) < ntaps[j])  // CHalfBandDecimateBy2's "safety net" (downconvert.cpp:361-362) would drop samples unfiltered
             return fail(PEBBLEGPU_E_SIZE, "dmFMS: a frame of %d samples is shorter than the RDS down-converter's stage %zu needs", block, j);
+    return 0;
+}
+
+int RdsCore::run(hipStream_t s, const float2 *in, long long in_pitch, long long n, const double *d_hilb, const int *d_list, int n_list, int block)
+{
+    if (!on || n_list == 0) return 0;
+    const size_t nst = des.stages.size();
+    if (int rc = check(n, block)) return rc;
+    if (block <= 0) block = (int)n;
     const dim3 blk(256);
     launch(k_rds_discrim, dim3((unsigned)cdiv_ll(n, 256), n_list), blk, s, in, in_pitch, n, (const RdsState *)d_state, reinterpret_cast<double *>(raw.data()), raw.pitch,
            d_list);

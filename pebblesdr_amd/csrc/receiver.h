@@ -281,6 +281,7 @@ struct RdsCore {
     int init(uint32_t channels, double demod_rate, long long max_n);
     void release();
     // queues the branch for the listed channels; block: demodulator-rate samples per processDataStereo call of the reference
+    int check(long long n, int block) const;   // the sizes run() accepts (the owner asks before it queues anything of the call)
     int run(hipStream_t s, const float2 *in, long long in_pitch, long long n, const double *d_hilb, const int *d_list, int n_list, int block);
     int collect(hipStream_t s, uint32_t ch);   // waits for the stream, replays the channel's new log entries
     int groups(hipStream_t s, uint32_t ch, RdsGroup *g, unsigned char *changed, uint32_t cap_out, uint32_t *n_out);

@@ -392,6 +392,24 @@ def test_wfm_stereo_rds_groups_in_the_receiver(gpu_lib, oracle_mod):
     assert got_c == list(want_c)
 
 
+def test_wfm_stereo_rds_refuses_what_the_branch_cannot_stream(gpu_lib):
+    """dmFMS calls must be whole numbers of the RDS down-converter's decimation (CDownConvert halves odd lengths stage by stage in the
+    reference -- not reproduced) and at least as long as its widest stage; a refused call leaves the object usable and dmFMM is not
+    affected."""
+    import pebblesdr_amd as P
+    fsw = 250000
+    d = P.Demod(64000, fsw, 4096)
+    d.setDemodMode(P.DM_FMS)
+    x = (0.5 * np.exp(2j * np.pi * 0.01 * np.arange(4096))).astype(np.complex128)
+    with pytest.raises(P.PebbleGpuError):
+        d.processBlock(x[:2052])          # 2052 = 8 * 256.5
+    assert d.processBlock(x[:2048]).shape == (2048,)
+    g, c = d.getNextRdsGroupData()
+    assert g.shape == (0, 4) and len(c) == 0
+    d.setDemodMode(P.DM_FMM)
+    assert d.processBlock(x[:2052]).shape == (2052,)
+
+
 def test_wfm_bank_rds_of_two_stations_in_one_stream(gpu_lib, oracle_mod):
     """Two broadcast multiplexes in one 2.5 Msps stream, a WFM bank of three channels off it -- dmFMS on the first station, dmFMM on it
     too, dmFMS on the second station: every dmFMS channel runs its own RDS branch (own down-converter history, PLL, block synchroniser
