@@ -21,7 +21,9 @@
  *     may be overwritten, only after pebblegpu_receiver_synchronize / pebblegpu_streambank_synchronize (or any of
  *     pebblegpu_memcpy_h2d / _d2h / pebblegpu_device_synchronize, which wait for all work queued on the device first).
  *     A host that touches those buffers with its own HIP calls must synchronise itself.  Calls on one handle execute in
- *     the order they were made.  The host-buffer entry points (pebblegpu_process_iq and every stand-alone step) return
+ *     the order they were made.  A receiver without a display transform runs a call as two overlapping stages on two streams
+ *     (two-stage calls) and bounds how far the host may run ahead: such a call returns once the call three
+ *     before it has completed.  The host-buffer entry points (pebblegpu_process_iq and every stand-alone step) return
  *     with their results complete.
  *   - the library owns every device buffer it returns; host pointers returned by *_result() stay
  *     valid until the next process call on the same handle (ProcessStep ownership rule,
