@@ -889,8 +889,8 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
         return fail(PEBBLEGPU_E_SIZE, "%lld samples is not a multiple of the decimation %u", n, chain.total);
     len0 = n / first.stride;
     // successive calls write successive output buffers (tail_job_out carries the consumer's look-back into the next one's head-room)
-    if (fin3.base) { std::swap(fin, fin2); std::swap(fin2, fin3); }  // (fin, fin2, fin3) <- (fin2, fin3, fin)
-    else if (fin2.base) std::swap(fin, fin2);
+    if (fin3.base && rotate3) { std::swap(fin, fin2); std::swap(fin2, fin3); }  // (fin, fin2, fin3) <- (fin2, fin3, fin)
+    else if (fin2.base) std::swap(fin, fin2);  // (either way the call writes what was fin2, whose head-room the last call's consumer filled)
     const HistBuf *src = &buf0;
     last_fused = false;
     last_mfma = false;

@@ -10,6 +10,7 @@
 // Receiver composes them the way Receiver::processIQData does; the stand-alone steps (steps.hip) wrap one
 // core each behind the reference's per-class call shapes.
 #pragma once
+#include <algorithm>
 #include <complex>
 #include <mutex>
 #include <vector>
@@ -179,6 +180,9 @@ struct DecimCore {
     // one's head-room.  tail_jobs() = tail_jobs_dec() (the decimator's own histories: its stream) + tail_job_out() (the consumer's stream)
     hipEvent_t done_event = nullptr;         // set by the caller before run(): an event to complete WITH the call's last launch when that is the bank kernel ...
     bool done_recorded = false;              // ... and whether run() did so (else the caller records it)
+    bool rotate3 = true;                     // this call rotates three output buffers (set by the caller before run(); ignored without fin3)
+    // a call of this many input samples is "long": chunks of 128 outputs or more, where two output buffers do as well as three
+    bool long_call(long long n) const { const long long lo = n / (long long)chain.total; return (lo + 2 * std::max(1LL, 1024LL / ((C + 31) / 32)) - 1) / (2 * std::max(1LL, 1024LL / ((C + 31) / 32))) >= 128; }
     HistBuf fin2, fin3;                      // fin: this call's; fin2: the next call's (its head-room filled by this call's consumer); fin3: a third, written by the call after that,
                                              // so that a call's decimator waits for the consumer of the call THREE back (long over) instead of two (often still running)
     int enable_double_out();                 // after init(); fails for a single-stage chain (its output is the first stage's buffer)
@@ -543,6 +547,7 @@ private:
     bool touched_ = true;             // a setter ran since the last call
     bool bank_pipe_ok_ = false;       // no display transform: the call's two stages (decimator | band-pass .. resampler) on the two streams, stage 2 beside the next call's stage 1
     hipEvent_t f_end_[3] = {nullptr, nullptr, nullptr};  // where stage 2 of the last three such calls ended
+    std::vector<std::pair<const void *, hipEvent_t>> out_reader_;  // per decimator output buffer: where the second stage that last read it ended
     hipEvent_t d_end_prev_ = nullptr;           // where the last call ended, if that was a two-stage call (the next one is timed from there)
     hipEvent_t sync_ev_[4] = {nullptr, nullptr, nullptr, nullptr};  // stage 1 -> stage 2 hand-over events (no timing), a ring
     hipEvent_t pipe_ev_ = nullptr;

@@ -438,8 +438,13 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         PG_HIP(hipStreamWaitEvent(chain_stream_, start, 0));  // fork: the input is ready where the call starts
     }
     // the output buffer this call writes was read three (two) calls ago (a wait is a queue packet: none when the host can see that it is over)
+    // three output buffers in rotation for short calls, two for long ones (chunks of 128 outputs or more: 0.917 / 0.923 ms per configs[2]
+    // call of 128 super-frames with two against 0.950-0.989 with three, the same at 32, 0.0775 against 0.0658 at 8)
+    const bool rot3 = bank_pipe && dec_.fin3.base && !dec_.long_call((long long)n);
+    dec_.rotate3 = rot3;
     {
-        hipEvent_t last_reader = dec_.fin3.base ? f_end_[2] : f_end_[1];  // (three output buffers: the call three back read the one this call writes)
+        hipEvent_t last_reader = nullptr;  // where the second stage that last read the buffer this call writes (dec_.fin2) ended
+        for (const auto &pr : out_reader_) if (pr.first == (const void *)dec_.fin2.base) last_reader = pr.second;
         if (bank_pipe && last_reader && hipEventQuery(last_reader) != hipSuccess) {
             // the host is more than two calls ahead of the device: it waits here (PEBBLEGPU_BANK_PIPE_HOSTWAIT=0: a wait in the queue instead,
             // one more packet between this decimator and the last)
@@ -529,8 +534,8 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         // (with two output buffers the next call's decimator becomes ready with the same event as this band-pass: a short nap lets its
         // one-wave-per-SIMD workgroups be placed before the band-pass fills the CUs -- placed behind them it ran 112 us instead of 65.
         // With three the next decimator is already running when this point is reached: no nap)
-        static const unsigned nap = [this] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_NAP_US"); return (unsigned)(100.0 * (e ? atof(e) : (dec_.fin3.base ? 0.0 : 8.0))); }();
-        if (int rc = run_nap(cs, nap)) return rc;
+        static const int nap_env = [] { const char *e = getenv("PEBBLEGPU_BANK_PIPE_NAP_US"); return e ? (int)(100.0 * atof(e)) : -1; }();
+        if (int rc = run_nap(cs, nap_env >= 0 ? (unsigned)nap_env : (rot3 ? 0u : 800u))) return rc;
     }
     const long long nd = dec_.out_len();
     if (zoom_bins) {  // SignalSpectrum::zoomed(m_sampleBuf, numStepSamples), receiver.cpp:884 / :942 (the update timer forced open)
@@ -630,6 +635,11 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         f_end_[2] = f_end_[1];
         f_end_[1] = f_end_[0];
         f_end_[0] = ev[6];
+        {   // this call's second stage reads the buffer the decimator has just written
+            bool found = false;
+            for (auto &pr : out_reader_) if (pr.first == (const void *)dec_.fin.base) { pr.second = ev[6]; found = true; }
+            if (!found) out_reader_.push_back({(const void *)dec_.fin.base, ev[6]});
+        }
         d_end_prev_ = ev[6];
     } else if (side && pipeline_) {
         // the call's two pipelines end separately: whoever needs both waits for both (sync(), the next call that is not plain)
