@@ -193,7 +193,7 @@ def settle(step, sync, max_s=0.5, batch=20):
     tens of milliseconds of sustained load to come up: the first 40 steps of the headline workload run at 0.35 ms, from step
     ~100 on at 0.29 (profiles/README.md), and 2 s of idleness resets that.  The W warm-up steps of the contract (a handful)
     would leave the K timed steps inside that ramp; a receive chain runs continuously, so the rate that means something is the
-    settled one.  Batches of `batch` steps with a device sync after each, until a batch is no more than 2 % faster than the one
+    settled one.  Batches of `batch` steps (at least 5 ms of work each) with a device sync after each, until a batch is no more than 2 % faster than the one
     before it or `max_s` seconds have passed; returns the number of steps run."""
     sync()
     prev, total = None, 0
@@ -208,6 +208,9 @@ def settle(step, sync, max_s=0.5, batch=20):
         if prev is not None and dt > prev * 0.98:
             break
         prev = dt
+        if dt * batch < 0.005:  # (a batch shorter than the ramp's own time scale would look settled at once: at least 5 ms of work each)
+            batch = int(0.005 / dt) + 1
+            prev = None
     return total
 
 

@@ -21,6 +21,9 @@ for c in range(C):
 n = k * rx.superframe
 rng = np.random.default_rng(1)
 x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * 0.05
+if os.environ.get("AB_INPUT") == "bench":  # the bench's input: tones in a sample of the channels + LCG noise
+    import bench
+    x = bench.make_bank_input(fs, n, [(c - C / 2) * (0.8 * fs / C) for c in range(C)], 3)
 buf = P.DeviceBuffer.from_array(x.view(np.float32))
 for _ in range(300):
     rx.process_device(buf.ptr, n)
