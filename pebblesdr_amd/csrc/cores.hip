@@ -648,6 +648,7 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
     }
     if (casc.nst > 0) {
         // largest power-of-two tile of final outputs whose two ping-pong buffers fit comfortably (<= 48 KiB)
+        const long long lds_cap = 48LL * 1024;
         int outb = 256;
         for (;; outb /= 2) {
             long long c0 = outb, c1 = 0;
@@ -656,7 +657,7 @@ int DecimCore::init(uint32_t channels, const design::Chain &c, long long max_in,
                 c0 = c0 * casc.stride[k - 1] + casc.ntaps[k - 1] - 1;
             }
             // c0 = stage-0 samples a tile reads, c1 = outputs of the first fused stage (the largest intermediate)
-            if ((c0 + c1) * (long long)sizeof(float2) <= 48 * 1024 || outb == 1) {
+            if ((c0 + c1) * (long long)sizeof(float2) <= lds_cap || outb == 1) {
                 casc.outb = outb;
                 casc.lds_half = (int)c0;
                 casc_lds_bytes = (size_t)(c0 + c1) * sizeof(float2);
@@ -966,12 +967,15 @@ int DecimCore::run(hipStream_t s, const float2 *d_in, long long in_pitch, bool s
             const RawSrc rs = raw ? *raw : RawSrc{nullptr, 0, 0, 0.f, 0};
             auto lean = !raw ? k_mix_hb11_lean<-1> : rs.fmt == 0 ? k_mix_hb11_lean<0> : rs.fmt == 1 ? k_mix_hb11_lean<1> : rs.fmt == 2 ? k_mix_hb11_lean<2>
                              : rs.fmt == 3 ? k_mix_hb11_lean<3> : k_mix_hb11_lean<4>;
-            launch(lean, dim3(cdiv(len0, 4LL * R * 64)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc,
-                   osc.a_inf, bank_taps, first.gain, osc.inline_dyn, R, j_first, rs);
+            static const bool edge_launch = [] { const char *e = getenv("PEBBLEGPU_LEAN_EDGE_LAUNCH"); return e && e[0] == '1'; }();  // A/B: the edges as a launch of their own
+            launch(lean, dim3(cdiv(len0, 4LL * R * 64) + (edge_launch ? 0 : 1)), dim3(256), s, d_in, buf0.data(), len0, (const ChanOsc *)osc.d_osc,
+                   osc.a_inf, bank_taps, first.gain, osc.inline_dyn, R, edge_launch ? -j_first : j_first, rs, (const float2 *)d_hist_mixed[hist_parity],
+                   d_hist_mixed[hist_parity ^ 1]);
             front_name = "k_mix_hb11_lean";
-            launch(raw ? k_mix_hb11_bank<false, false, true> : k_mix_hb11_bank<false, false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch,
-                   (int)shared_input, buf0.data(), buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1],
-                   (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first, rs);
+            if (edge_launch)
+                launch(raw ? k_mix_hb11_bank<false, false, true> : k_mix_hb11_bank<false, false, false>, dim3(len0 / (4LL * R * 64) != 0 ? 2 : 1, 1), dim3(256), s, d_in, in_pitch,
+                       (int)shared_input, buf0.data(), buf0.pitch, len0, (const ChanOsc *)osc.d_osc, (const float2 *)d_hist_mixed[hist_parity], d_hist_mixed[hist_parity ^ 1],
+                       (int)kMaxTaps, (const float *)osc.d_amp, osc.a_inf, bank_taps, first.gain, osc.inline_dyn, 0, (int)C, R, j_first, rs);
         } else if (bank_front && (C >= 16 ? shared_input : want_lds_free)) {
  // a bank off one shared stream: lanes = channels, windows in registers (k_mix_hb11_bank)
             int cl_log2 = 0;

@@ -628,11 +628,12 @@ static __global__ __launch_bounds__(256) void k_mix_hb11_bank(const float2 *__re
 // general kernels); and the oscillator factored out of the window, y[j] = gain * pa(j) * sum_d (h[d] step[d]) x[S j - 10 + d]
 // with pa(j) = a_inf e^{j 2 pi (phase0 + (S j - 9) inc)}: seven complex MACs and one product per output instead of
 // thirteen products and seven MACs.
-// grid ceil(n_out / (4 R 64)), block 256 (four independent waves, R outputs per lane each).
+// grid ceil(n_out / (4 R 64)) + 1 (the last workgroup: the call's edges), block 256 (four independent waves, R outputs per lane each).
 template <int FMT /* >= 0: raw device-format input (RawSrc, that sample format) converted in the window loads; -1: float2 `in` */>
 static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *__restrict__ in, float2 *__restrict__ out, long long n_out,
                                                                   const ChanOsc *__restrict__ osc, float a_inf, FrontTaps hb, float out_gain,
-                                                                  OscDynInline dyn, int R, long long j_first, RawSrc raw)
+                                                                  OscDynInline dyn, int R, long long j_first, RawSrc raw,
+                                                                  const float2 *__restrict__ hist, float2 *__restrict__ hist_out)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = hb.stride;
@@ -640,6 +641,42 @@ static __global__ __launch_bounds__(256, 8) void k_mix_hb11_lean(const float2 *_
     const double inc = oc->inc;
     const double phase0 = dyn.use ? dyn.d[0].phase0 : oc->phase0;
     const bool mix = (dyn.use ? dyn.d[0].mix_on : oc->mix_on) != 0;
+    const bool own_edges = j_first >= 0;  // (A/B: a negative j_first leaves the edges to a launch of k_mix_hb11_bank)
+    if (!own_edges) j_first = -j_first;
+    if (own_edges && blockIdx.x == gridDim.x - 1) {
+        // The launch's last workgroup does what the outputs' lanes leave out -- the first j_first outputs, whose windows reach back into
+        // the previous call's mixed samples (`hist`, ten of them), and the ten mixed samples this call leaves for the next (`hist_out`) --
+        // with k_mix_hb11_bank's arithmetic (that kernel used to be launched behind this one for it, two workgroups that did not fit
+        // beside the display transform's: 60 us on the chain's critical path for a microsecond of work).
+        const int t = threadIdx.x;
+        if (t < (int)j_first) {
+            const long long i0 = (long long)S * t - 10;
+            const float2 pa = mix ? cscale(cis_cycles(phase0 + (double)(i0 + 1) * inc), a_inf) : make_float2(1.f, 0.f);
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const int d = q < 3 ? 2 * q : q == 3 ? 5 : 2 * q - 2;  // 0 2 4 5 6 8 10
+                const long long i = i0 + d;
+                float2 m;
+                if (i < 0) {
+                    m = hist[10 + i];
+                } else {
+                    m = FMT >= 0 ? raw_load(raw, i) : in[i];
+                    if (mix) m = cmul(d == 0 ? pa : cmul(oc->step[d], pa), m);
+                }
+                if (q == 0) acc = cscale(m, hb.h[0]);
+                else { acc.x = fmaf(m.x, hb.h[d], acc.x); acc.y = fmaf(m.y, hb.h[d], acc.y); }
+            }
+            out[t] = cscale(acc, out_gain);
+        }
+        if (t >= 64 && t < 74) {
+            const long long i = n_out * S - 10 + (t - 64);
+            float2 v = FMT >= 0 ? raw_load(raw, i) : in[i];
+            if (mix) v = cmul(cscale(cis_cycles(phase0 + (double)(i + 1) * inc), a_inf), v);
+            hist_out[t - 64] = v;
+        }
+        return;
+    }
     float2 c2 = make_float2(hb.h[2], 0.f), c4 = make_float2(hb.h[4], 0.f), c5 = make_float2(hb.h[5], 0.f), c6 = make_float2(hb.h[6], 0.f),
            c8 = make_float2(hb.h[8], 0.f), c10 = make_float2(hb.h[10], 0.f);
     if (mix) {
