@@ -2266,6 +2266,54 @@ def test_two_stage_calls_back_to_back_equal_single_stream_calls(gpu_lib, monkeyp
             bf.free()
 
 
+def test_two_stage_calls_in_long_runs_of_mixed_lengths(gpu_lib, monkeypatch):
+    """The rotation of the decimator's output buffers under load: forty calls of 1, 2 and 16 super-frames (from 16 on a 256-channel bank
+    rotates two buffers instead of three, with the nap in front of its second stage) in runs of one to seven queued back to back --
+    more calls in flight than there are buffers, so the host's wait for the second stage that last read the buffer about to be
+    written is exercised -- against the single-stream receiver after every run, bit for bit."""
+    import pebblesdr_amd as P
+    fs, C, KM = 2_048_000, 256, 16
+    # (one wave per SIMD on both sides: by itself the single-stream receiver gives a long call two, i.e. other chunk boundaries and with
+    # them other points where the oscillator's phase is set exactly instead of rotated -- 4e-9 of the output, not a bit-for-bit twin)
+    monkeypatch.setenv("PEBBLEGPU_BANK_WAVES", "1")
+    monkeypatch.setenv("PEBBLEGPU_BANK_PIPELINE", "0")
+    b = P.ReceiverBank(fs, C, True, False, 0, max_superframes=KM)
+    monkeypatch.delenv("PEBBLEGPU_BANK_PIPELINE")
+    a = P.ReceiverBank(fs, C, True, False, 0, max_superframes=KM)
+    fcs = [(-0.4 + 0.8 * (c + 0.5) / C) * fs for c in range(C)]
+    for rx in (a, b):
+        for c in range(C):
+            rx.set_mode(c, P.DM_USB); rx.set_mixer(c, fcs[c]); rx.set_bandpass(c, 300, 3000)
+    sf = a.superframe
+    rng = np.random.default_rng(17)
+    pool = {}
+    for k in (1, 2, KM):  # one input per call length, reused (the chain carries its state from call to call either way)
+        x = (tones(fs, k * sf, [(0.05, fc + 900.0 + 30.0 * i) for i, fc in enumerate(fcs[::32])]) + lcg_noise(k * sf, 20 + k, 1e-2)).astype(np.complex64)
+        pool[k] = P.DeviceBuffer.from_array(P.binding.to_f32_iq(x), 0)
+    try:
+        lens = [int(v) for v in rng.choice([1, 1, 2, 2, 2, KM], size=40)]
+        lens[5] = lens[6] = KM  # two long calls in a row, then short ones again
+        i = 0
+        while i < len(lens):
+            run = int(rng.integers(1, 8))
+            group = lens[i:i + run]
+            for k in group:
+                b.process_device(pool[k].ptr, k * sf)
+            b.synchronize()
+            want = b.audio().copy()
+            for k in group:
+                a.process_device(pool[k].ptr, k * sf)
+            a.synchronize()
+            got = a.audio()
+            assert got.shape == want.shape and np.abs(want).max() > 1e-3
+            assert np.array_equal(got, want), "after call %d (run of %d, lengths %s): rel rms %g" % (i + len(group) - 1, len(group), group, rel_rms(got, want))
+            i += len(group)
+        assert a.kernel_name(2) == "k_mix_dec_mfma"
+    finally:
+        for bf in pool.values():
+            bf.free()
+
+
 def test_decimator_inside_the_display_transform_switches_routes_with_a_retune(gpu_lib, monkeypatch):
     """PEBBLEGPU_FUSE_DEC=1: calls inside an oscillator transient (the first one, the one after a retune) take the stand-alone
     kernels, the others run the decimator inside k_spectrum_t128 -- each route leaves what the other needs in front of the next call
