@@ -157,7 +157,7 @@ int pebblegpu_set_bandpass(pebblegpu_receiver *rx, uint32_t channel, double lo_h
  * m_RdsDownConvert, the 2400 Hz low-pass, processRdsPll, the biphase matched filter, the bit-rate resonator and slicer,
  * processNewRdsBit's block synchroniser with its burst corrector) runs for every dmFMS channel, in double on the device; its groups are
  * read through pebblegpu_receiver_rds_groups.  Calls and frames of a dmFMS bank must be multiples of the RDS down-converter's
- * decimation (8 at the demodulator rates between 250 and 500 kHz) and at least as long as its widest stage.  Not reproduced: what the GUI makes of a group (rdsdecode.cpp). */
+ * decimation (8 up to 312.5 kHz of demodulator rate, 16 from 390.625 kHz on) and at least as long as its widest stage.  Not reproduced: what the GUI makes of a group (rdsdecode.cpp). */
 int pebblegpu_set_demod_mode(pebblegpu_receiver *rx, uint32_t channel, int mode);
 /* tRDS_GROUPS (application/demod/rbdsconstants.h) */
 typedef struct pebblegpu_rds_group { uint16_t block_a, block_b, block_c, block_d; } pebblegpu_rds_group;
