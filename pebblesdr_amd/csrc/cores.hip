@@ -1251,6 +1251,7 @@ int AmCore::set_list(hipStream_t s, const std::vector<int> &am_channels)
 }
 int AmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n, Gate gate)
 {
+    last_n = 0;
     if (list.empty()) return 0;
     if (n > tmp.cap) return fail(PEBBLEGPU_E_SIZE, "%lld samples exceed this object's capacity", n);
     if (n < tmp.hist) return fail(PEBBLEGPU_E_SIZE, "AM demod needs at least %d samples per call", tmp.hist);
@@ -1262,7 +1263,8 @@ int AmCore::run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out
            (int)nsub, -1, (const int *)d_list, gate);
     launch(k_fir_dec, dim3(cdiv(n, 256), na), dim3(256), s, (const float2 *)tmp.data(), tmp.pitch, out, out_pitch, n, 1,
            (const float *)d_taps, (const float *)nullptr, (int)kMaxTaps, (const int *)d_ntaps, 0, 1.0f, 0, (const int *)d_list, gate);
-    launch(k_save_tail, dim3(cdiv(tmp.hist, 256), na), dim3(256), s, tmp.data(), tmp.pitch, n, tmp.hist, (const int *)d_list, gate);
+    last_n = n;
+    if (!defer_tail) launch(k_save_tail, dim3(cdiv(tmp.hist, 256), na), dim3(256), s, tmp.data(), tmp.pitch, n, tmp.hist, (const int *)d_list, gate);
     PG_HIP(hipGetLastError());
     return 0;
 }

@@ -227,6 +227,11 @@ struct AmCore {
     int set_list(hipStream_t s, const std::vector<int> &am_channels);
     // in/out rows may be the same buffer (the scan reads `in`, the FIR writes `out`)
     int run(hipStream_t s, const float2 *in, long long in_pitch, float2 *out, long long out_pitch, long long n, Gate gate = Gate{nullptr, 0, 0});
+    // defer_tail: run() leaves the refresh of tmp's head-room to the caller's tail launch (tail_jobs: every row, also those of channels
+    // that are not AM -- harmless; not for gated calls, whose closed channels keep their history)
+    bool defer_tail = false;
+    long long last_n = 0;
+    void tail_jobs(std::vector<TailJob> &jobs) const { if (defer_tail && !list.empty() && last_n > 0) jobs.push_back(TailJob{tmp.data(), tmp.pitch, last_n, tmp.hist, 0, nullptr, 0}); }
 };
 
 // ---- Demod_NFM / Demod_SAM (PLL demodulators) ----

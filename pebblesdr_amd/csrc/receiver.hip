@@ -581,6 +581,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
             float2 *seg = audio.data() + (long long)j * spf;
             if (int rc = anf_.run(cs, seg, audio.pitch, spf, gate)) return rc;
             if (int rc = agc_.run(cs, seg, audio.pitch, spf, gate)) return rc;
+            am_.defer_tail = false;
             if (int rc = am_.run(cs, seg, audio.pitch, seg, audio.pitch, spf, gate)) return rc;
             if (sam_.C) { if (int rc = sam_.run(cs, seg, audio.pitch, seg, audio.pitch, spf, gate)) return rc; }
             if (nfm_.C) { if (int rc = nfm_.run(cs, seg, audio.pitch, seg, audio.pitch, spf, gate)) return rc; }
@@ -592,6 +593,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
         if (int rc = anf_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // NoiseFilter::ProcessBlock, receiver.cpp:974
         if (int rc = agc_.run(cs, audio.data(), audio.pitch, nd)) return rc;  // AGC::processBlock, receiver.cpp:983
         // Demod::processBlock, receiver.cpp:987: AM channels are demodulated in place; every other narrow mode returns its input
+        am_.defer_tail = bank_pipe;  // (a two-stage call's tail launch carries the AM demodulator's history refresh: one launch fewer)
         if (int rc = am_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc;
         if (sam_.C) { if (int rc = sam_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
         if (nfm_.C) { if (int rc = nfm_.run(cs, audio.data(), audio.pitch, audio.data(), audio.pitch, nd)) return rc; }
@@ -618,6 +620,7 @@ int Receiver::process(const float2 *d_iq, uint64_t n, bool with_spectrum, bool w
     if (bank_pipe) {
         std::vector<TailJob> jobs;
         dec_.tail_job_out(jobs);
+        am_.tail_jobs(jobs);
         if (int rc = run_save_tails(cs, jobs, C, nullptr)) return rc;
     } else if (!tails_carried) {  // one launch refreshes every history head-room for the next call
         std::vector<TailJob> jobs;
