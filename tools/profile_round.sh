@@ -29,5 +29,7 @@ bash tools/run_sq_counters.sh ${tag}_cic_dec k_mix_dec_mfma tools/pmc_bank.py 3 
 bash tools/run_sq_counters.sh ${tag}_big256_rows k_big256_rows tools/pmc_streambank.py > /dev/null
 bash tools/run_sq_counters.sh ${tag}_big256_cols k_big256_cols tools/pmc_streambank.py > /dev/null
 bash tools/run_sq_counters.sh ${tag}_fastfir k_fastfir_t128 tools/pmc_streambank.py > /dev/null
+# kernel timelines of the two-stage calls (two output buffers against three)
+bash tools/timeline_two_stage.sh > /dev/null 2>&1 || true
 rm -rf $o/${tag}_trace $o/${tag}_pmc_* $o/${tag}_fused_dec $o/${tag}_cic_dec $o/${tag}_big256_rows $o/${tag}_big256_cols $o/${tag}_fastfir
 ls -la $o | grep ${tag}_
